@@ -1,0 +1,1137 @@
+/* oracle/tfrec_oracle.c
+ *
+ * TEST INFRASTRUCTURE ONLY.  Plain-C CPU restatement of the baycom/tfrec IQ->telegram hot path, used
+ * as the parity checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing
+ * in the product (tfrec_amd/, include/) may link, import or call this file.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit against the real reference
+ * compiled from /root/reference (oracle/_ref/ref_driver, see oracle/Makefile) on synthetic streams
+ * (decimated int16 samples, per-flush rdata/byte_cnt/rssi/offset/sample position, store_data records,
+ * printed telegram lines), against the reference's only in-tree known answer (README.md:123) and the
+ * byte-level known answers of SURVEY.md Appendix D; the minted vectors live in tests/golden/.
+ *
+ * "Normative build": the reference Makefile compiles with -O3 -ffast-math (Makefile:11-20).  g++ 11.4
+ * re-associates two fp64 expressions under those flags; this file follows the arithmetic of that
+ * binary (verified by disassembly and by bit-exact probes through ref_driver):
+ *   - iir2::step  (dsp_stuff.cpp:47-56)  evaluates ((b2*dn2 + a1*yn1) + (b0*dn + b1*dn1)) + a2*yn2
+ *   - iir2::set   (dsp_stuff.cpp:36-45)  evaluates b0 = 1/((i+s)*i+1), a2 = ((s-i)*i-1)*b0
+ *   - fm_dev      (dsp_stuff.cpp:284-292) evaluates (int)(atan2(cj,cr) * (16384/M_PI))
+ *   - whb rssi    (whb.cpp:696)           evaluates 10*log10(rssi*0.00025 + 1)
+ *   - every x/10 and x/10.0 of the telegram field maths (tfa1.cpp:63, tfa2.cpp:113-139, 233,
+ *     whb.cpp:109-123, 346-347) is x*0.1
+ * Build this file with -fno-fast-math -ffp-contract=off (oracle/Makefile does).
+ *
+ * Members the reference leaves uninitialised (last_i/last_q of every demodulator, whb avg_of, rdata;
+ * tfa1.cpp:136-141, tfa2.cpp:316-323, whb.cpp:605-614) are defined as 0 here, as in ref_driver.
+ */
+#define _GNU_SOURCE
+#include "tfrec_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- helpers */
+
+/* (int)double as x86 cvttsd2si does it: NaN/inf/out of range -> INT_MIN. */
+static int d2i(double v)
+{
+	if (!(v > -2147483649.0 && v < 2147483648.0))
+		return INT_MIN;
+	return (int)v;
+}
+
+typedef struct {
+	char *p;
+	size_t len, cap;
+} sbuf_t;
+
+static void sb_printf(sbuf_t *s, const char *fmt, ...)
+{
+	va_list ap;
+	char tmp[1024];
+	va_start(ap, fmt);
+	int n = vsnprintf(tmp, sizeof(tmp), fmt, ap);
+	va_end(ap);
+	if (n < 0)
+		return;
+	if ((size_t)n >= sizeof(tmp))
+		n = sizeof(tmp) - 1;
+	if (s->len + n + 1 > s->cap) {
+		s->cap = (s->cap + n + 1) * 2 + 256;
+		s->p = (char *)realloc(s->p, s->cap);
+	}
+	memcpy(s->p + s->len, tmp, n);
+	s->len += n;
+	s->p[s->len] = 0;
+}
+
+/* ---------------------------------------------------------------- CRC (crc8.cpp:4-28, crc32.cpp:4-30) */
+
+static uint8_t crc8_tab[256];
+static uint32_t crc32_tab[256];
+static int tabs_ready;
+
+static void build_tabs(void)
+{
+	if (tabs_ready)
+		return;
+	for (int n = 0; n < 256; n++) {
+		/* CRC-8, poly 0x31, MSB first */
+		uint8_t t = (uint8_t)n;
+		for (int m = 0; m < 8; m++)
+			t = (t & 0x80) ? (uint8_t)((t << 1) ^ 0x31) : (uint8_t)(t << 1);
+		crc8_tab[n] = t;
+		/* CRC-32, poly 0x04c11db7, MSB first: the reference shifts the byte value up 32 times
+		 * from the low end (crc32.cpp:10-14), which equals the usual table entry for n<<24. */
+		uint32_t u = (uint32_t)n;
+		for (int m = 0; m < 32; m++)
+			u = (u & 0x80000000u) ? ((u << 1) ^ 0x04c11db7u) : (u << 1);
+		crc32_tab[n] = u;
+	}
+	tabs_ready = 1;
+}
+
+uint8_t orc_crc8(const uint8_t *d, int len)
+{
+	build_tabs();
+	uint8_t c = 0;
+	for (int n = 0; n < len; n++)
+		c = crc8_tab[c ^ d[n]];
+	return c;
+}
+
+uint32_t orc_crc32(const uint8_t *d, int len, uint32_t init)
+{
+	build_tabs();
+	uint32_t c = init;
+	for (int n = 0; n < len; n++)
+		c = (c << 8) ^ crc32_tab[(c >> 24) ^ d[n]];
+	return c;
+}
+
+/* ---------------------------------------------------------------- biquad (dsp_stuff.cpp:28-56) */
+
+typedef struct {
+	double dn1, dn2, yn, yn1, yn2;
+	double b0, b1, b2, a1, a2;
+} iir_t;
+
+void orc_iir_coeffs(double cutoff, double out[5])
+{
+	/* arithmetic of the normative binary, see file header */
+	double i = 1.0 / tan(cutoff * M_PI);
+	double s = sqrt(2.0);
+	double b0 = 1.0 / ((i + s) * i + 1.0);
+	double t = i * i - 1.0;
+	out[0] = b0;
+	out[1] = b0 + b0;
+	out[2] = b0;
+	out[3] = (t + t) * b0;
+	out[4] = ((s - i) * i - 1.0) * b0;
+}
+
+static void iir_init(iir_t *f, double cutoff)
+{
+	double c[5];
+	memset(f, 0, sizeof(*f));
+	orc_iir_coeffs(cutoff, c);
+	f->b0 = c[0];
+	f->b1 = c[1];
+	f->b2 = c[2];
+	f->a1 = c[3];
+	f->a2 = c[4];
+}
+
+static double iir_step(iir_t *f, double dn)
+{
+	double y1 = f->yn, y2 = f->yn1;
+	double y = ((f->b2 * f->dn2 + f->a1 * y1) + (f->b0 * dn + f->b1 * f->dn1)) + f->a2 * y2;
+	f->yn2 = y2;
+	f->yn1 = y1;
+	f->yn = y;
+	f->dn2 = f->dn1;
+	f->dn1 = dn;
+	return y;
+}
+
+void orc_iir_run(double cutoff, const double *in, double *out, size_t n)
+{
+	iir_t f;
+	iir_init(&f, cutoff);
+	for (size_t k = 0; k < n; k++)
+		out[k] = iir_step(&f, in[k]);
+}
+
+/* ---------------------------------------------------------------- discriminators (dsp_stuff.cpp:269-292) */
+
+int orc_fm_dev_nrzs(int ar, int aj, int br, int bj)
+{
+	int cr = (int)((uint32_t)(ar * br) + (uint32_t)(aj * bj));
+	if (cr > 1000000000)
+		cr = 1000000000;
+	if (cr < -1000000000)
+		cr = -1000000000;
+	return cr;
+}
+
+static uint64_t g_uncertain; /* diagnostics only, see orc_atan_uncertain() */
+
+int orc_fm_dev(int ar, int aj, int br, int bj)
+{
+	double cr = ((double)ar) * br + ((double)aj) * bj;
+	double cj = ((double)aj) * br - ((double)ar) * bj;
+	double v = atan2(cj, cr) * (16384.0 * (1.0 / M_PI));
+	double fr = v - trunc(v);
+	if (fr < 0)
+		fr = -fr;
+	if ((fr < 1e-6 || fr > 1.0 - 1e-6) && !(cj == 0 || cr == 0 || cj == cr || cj == -cr))
+		g_uncertain++;
+	return d2i(v);
+}
+
+/* ---------------------------------------------------------------- decimator (dsp_stuff.cpp:61-264) */
+
+/* tap values: dsp_stuff.cpp:61-88 (narrow), :91-117 (wide), :119-130 (first stage) */
+static const int16_t taps_s2_narrow[20] = { -1087, -1082, -1065, -451, 912, 2997, 5556, 8157, 10285, 11484,
+					    11484, 10285, 8157, 5556, 2997, 912, -451, -1065, -1082, -1087 };
+static const int16_t taps_s2_wide[20] = { 546, 451, -317, -1844, -3198, -2817, 494, 6469, 13074, 17421,
+					  17421, 13074, 6469, 494, -2817, -3198, -1844, -317, 451, 546 };
+static const int16_t taps_s1[8] = { 2443, 6339, 11036, 14254, 14254, 11036, 6339, 2443 };
+
+typedef struct {
+	int16_t h1[8];  /* last 8 inputs of stage 1 (dsp_stuff.cpp:204-230) */
+	int16_t h2[20]; /* last 20 inputs of stage 2 (dsp_stuff.cpp:172-202) */
+} chan_hist_t;
+
+/* one channel, one block: x has n samples at stride 2; writes n/4 outputs at stride 2 into y */
+static void decimate_channel(chan_hist_t *h, const int16_t *x, int n, const int16_t *t2, int16_t *y)
+{
+	int m = 0;
+	int16_t s1out[2];
+	for (int k = 0; k < n; k += 2) {
+		/* stage 1: shift in two samples, 8 taps, per-tap arithmetic >>16, int16 store */
+		memmove(h->h1, h->h1 + 2, 6 * sizeof(int16_t));
+		h->h1[6] = x[2 * k];
+		h->h1[7] = x[2 * (k + 1)];
+		int32_t sum = 0;
+		for (int n1 = 0; n1 < 8; n1++)
+			sum += (h->h1[n1] * taps_s1[n1]) >> 16;
+		s1out[(k >> 1) & 1] = (int16_t)sum;
+		if ((k >> 1) & 1) {
+			/* stage 2 consumes two stage-1 outputs */
+			memmove(h->h2, h->h2 + 2, 18 * sizeof(int16_t));
+			h->h2[18] = s1out[0];
+			h->h2[19] = s1out[1];
+			int32_t acc = 0;
+			for (int n2 = 0; n2 < 20; n2++)
+				acc += (h->h2[n2] * t2[n2]) >> 16;
+			y[2 * m] = (int16_t)acc;
+			m++;
+		}
+	}
+}
+
+void orc_decimate(const uint8_t *iq, size_t n_complex, int wide, int16_t *out)
+{
+	chan_hist_t hi, hq;
+	memset(&hi, 0, sizeof(hi));
+	memset(&hq, 0, sizeof(hq));
+	const int16_t *t2 = wide ? taps_s2_wide : taps_s2_narrow;
+	enum { CH = 4096 };
+	int16_t x[2 * CH];
+	size_t done = 0;
+	while (done < n_complex) {
+		size_t n = n_complex - done;
+		if (n > CH)
+			n = CH;
+		for (size_t k = 0; k < 2 * n; k++)
+			x[k] = (int16_t)(((int)iq[2 * done + k] - 128) << 6); /* engine.cpp:78 */
+		decimate_channel(&hi, x, (int)n, t2, out + 2 * (done / 4));
+		decimate_channel(&hq, x + 1, (int)n, t2, out + 2 * (done / 4) + 1);
+		done += n;
+	}
+}
+
+/* ---------------------------------------------------------------- decoders */
+
+enum { T_TFA_1 = 0, T_TFA_2 = 1, T_TFA_3 = 2, T_TX22 = 3, T_TFA_WHB = 5 };
+
+typedef struct {
+	int slot;
+	int type;
+	int synced;
+	int byte_cnt;
+	uint8_t rdata[256];
+	uint32_t sr;
+	int sr_cnt;
+	int invert;                          /* tfa2 */
+	int last_bit, psk, last_psk, nrzs;   /* whb */
+	uint32_t lfsr;                       /* whb */
+	/* bit log since last flush */
+	unsigned char *bits;
+	size_t nbits, capbits;
+} dec_t;
+
+struct orc;
+static void emit_data(struct orc *o, dec_t *d, int type, uint64_t id, double temp, double hum, int seq, int alarm,
+		      int rssi);
+
+/* ---------------------------------------------------------------- demodulators */
+
+typedef struct {
+	int kind; /* 0 tfa1, 1 tfa2-family, 2 whb */
+	dec_t dec;
+	int last_bit_idx;
+	int timeout_cnt;
+	int last_i, last_q;
+	/* tfa1 */
+	int mark_lvl;
+	int rssi_i;
+	/* tfa2 */
+	double spb, est_spb;
+	int bitcnt, dmin, dmax, offset, last_bit;
+	iir_t iir;
+	/* whb */
+	int last_dev, avg_of;
+	uint64_t step, last_peak;
+	double rssi_d;
+	iir_t iir_avg;
+} dem_t;
+
+struct orc {
+	int ndem;
+	dem_t dem[ORC_NSLOTS];
+	int wide;
+	chan_hist_t hi, hq;
+	/* fsk_demod state (fm_demod.cpp:18-32) */
+	int thresh, thresh_mode, triggered_avg, runs;
+	long block;
+	int cur_index;
+	int log_bits, keep_dec, quiet;
+	orc_event_t *ev;
+	size_t nev, capev;
+	orc_data_t *data;
+	size_t ndata, capdata;
+	sbuf_t text, bitstext;
+	int16_t *dec;
+	size_t ndec, capdec;
+};
+
+static void dec_init(dec_t *d, int slot, int type)
+{
+	memset(d, 0, sizeof(*d));
+	d->slot = slot;
+	d->type = type;
+	d->sr_cnt = -1;
+}
+
+static void log_bit(orc_t *o, dec_t *d, int bit)
+{
+	if (!o->log_bits || o->quiet)
+		return;
+	if (d->nbits == d->capbits) {
+		d->capbits = d->capbits * 2 + 1024;
+		d->bits = (unsigned char *)realloc(d->bits, d->capbits);
+	}
+	d->bits[d->nbits++] = (unsigned char)bit;
+}
+
+/* tfa1.cpp:120-134 */
+static void tfa1_store_bit(orc_t *o, dec_t *d, int bit)
+{
+	log_bit(o, d, bit);
+	d->sr = (d->sr >> 1) | ((uint32_t)bit << 31);
+	if ((d->sr & 0xffff) == 0xd42d) {
+		d->sr_cnt = 0;
+		d->byte_cnt = 0;
+	}
+	if (d->sr_cnt == 0) {
+		if (d->byte_cnt < 256)
+			d->rdata[d->byte_cnt] = d->sr & 0xff;
+		d->byte_cnt++;
+	}
+	if (d->sr_cnt >= 0)
+		d->sr_cnt = (d->sr_cnt + 1) & 7;
+}
+
+/* tfa2.cpp:281-314 */
+static void tfa2_store_bit(orc_t *o, dec_t *d, int bit)
+{
+	log_bit(o, d, bit);
+	d->sr = (d->sr << 1) | (uint32_t)bit;
+	if ((d->sr & 0xffff) == 0x2dd4) {
+		d->sr_cnt = 0;
+		d->rdata[0] = (d->sr >> 8) & 0xff;
+		d->byte_cnt = 1;
+		d->invert = 0;
+	}
+	if (((~d->sr) & 0xffff) == 0x2dd4) {
+		if (!o->quiet)
+			sb_printf(&o->text, "Inverted SYNC\n");
+		d->sr_cnt = 0;
+		d->rdata[0] = (uint8_t) ~((d->sr >> 8) & 0xff);
+		d->byte_cnt = 1;
+		d->invert = 1;
+	}
+	if (d->sr_cnt == 0) {
+		if (d->byte_cnt < 256)
+			d->rdata[d->byte_cnt] = d->invert ? (uint8_t) ~(d->sr & 0xff) : (uint8_t)(d->sr & 0xff);
+		d->byte_cnt++;
+	}
+	if (d->sr_cnt >= 0)
+		d->sr_cnt = (d->sr_cnt + 1) & 7;
+}
+
+/* whb.cpp:566-603 */
+static void whb_store_bit(orc_t *o, dec_t *d, int bit)
+{
+	log_bit(o, d, bit);
+	if (bit == d->last_bit)
+		d->psk = 1 - d->psk;
+	if (d->psk == d->last_psk)
+		d->nrzs = 1 - d->nrzs;
+	d->last_bit = bit;
+	d->last_psk = d->psk;
+	int out = d->nrzs ^ ((d->lfsr >> 16) & 1) ^ ((d->lfsr >> 11) & 1);
+	d->lfsr = (d->lfsr << 1) | (uint32_t)d->nrzs;
+	d->sr = (d->sr >> 1) | ((uint32_t)out << 31);
+	if (d->sr == 0x2bd42d4bu) {
+		d->synced = 1;
+		d->sr_cnt = 0;
+		d->rdata[0] = d->sr & 0xff;
+		d->rdata[1] = (d->sr >> 8) & 0xff;
+		d->rdata[2] = (d->sr >> 16) & 0xff;
+		d->byte_cnt = 3;
+	}
+	if (d->sr_cnt == 0) {
+		if (d->byte_cnt < 256)
+			d->rdata[d->byte_cnt] = (d->sr >> 24) & 0xff;
+		d->byte_cnt++;
+	}
+	if (d->sr_cnt >= 0)
+		d->sr_cnt = (d->sr_cnt + 1) & 7;
+}
+
+static void log_event(orc_t *o, dec_t *d, int rssi_db, int offset, int64_t rssi_raw)
+{
+	if (o->quiet)
+		return;
+	if (o->log_bits) {
+		sb_printf(&o->bitstext, "W %i %zu ", d->slot, d->nbits);
+		for (size_t n = 0; n < d->nbits; n++)
+			sb_printf(&o->bitstext, "%c", '0' + d->bits[n]);
+		sb_printf(&o->bitstext, "\n");
+		d->nbits = 0;
+	}
+	if (o->nev == o->capev) {
+		o->capev = o->capev * 2 + 256;
+		o->ev = (orc_event_t *)realloc(o->ev, o->capev * sizeof(orc_event_t));
+	}
+	orc_event_t *e = &o->ev[o->nev++];
+	memset(e, 0, sizeof(*e));
+	e->slot = d->slot;
+	e->byte_cnt = d->byte_cnt;
+	e->rssi_db = rssi_db;
+	e->offset = offset;
+	e->end_sample = (int64_t)o->block * ORC_BLOCK_DEC + o->cur_index / 2;
+	e->rssi_raw = rssi_raw;
+	memcpy(e->rdata, d->rdata, 64);
+}
+
+static void emit_data(orc_t *o, dec_t *d, int type, uint64_t id, double temp, double hum, int seq, int alarm, int rssi)
+{
+	if (o->quiet)
+		return;
+	if (o->ndata == o->capdata) {
+		o->capdata = o->capdata * 2 + 256;
+		o->data = (orc_data_t *)realloc(o->data, o->capdata * sizeof(orc_data_t));
+	}
+	orc_data_t *r = &o->data[o->ndata++];
+	r->slot = d->slot;
+	r->type = type;
+	r->id = id;
+	r->temp = temp;
+	r->humidity = hum;
+	r->sequence = seq;
+	r->alarm = alarm;
+	r->rssi = rssi;
+	r->flags = 0;
+}
+
+#define TXT(o, ...)                                  \
+	do {                                         \
+		if (!(o)->quiet)                     \
+			sb_printf(&(o)->text, __VA_ARGS__); \
+	} while (0)
+
+/* tfa1.cpp:47-118 */
+static void tfa1_flush(orc_t *o, dec_t *d, int rssi)
+{
+	uint8_t *r = d->rdata;
+	if (d->byte_cnt >= 10) {
+		int id = ((r[2] << 8) | r[3]) & 0x7fff;
+		int batfail = (r[7] & 0x80) >> 7;
+		double temp = ((r[4] & 0xf) * 100) + ((r[5] >> 4) * 10) + (r[5] & 0xf);
+		temp = (temp * 0.1) - 40; /* fast-math: /10 is *0.1 in the normative binary */
+		int hum = r[6];
+		int seq = r[8] >> 4;
+		uint8_t crc_val = r[10];
+		uint8_t crc_calc = orc_crc8(&r[2], 8);
+		if (crc_val == crc_calc && ((r[4] & 0xf0) == 0x80 || hum == 0x7f || hum == 0x6a) && hum <= 0x7f &&
+		    (r[7] & 0x60) == 0x60 && (r[8] & 0xf) == 0 && r[9] == 0x56) {
+			if (hum == 0x6a)
+				hum = 0;
+			if (r[5] == 0xff || r[5] == 0xaa || hum == 0x7f) {
+				batfail = 2;
+				hum = 0;
+				temp = 0;
+			}
+			TXT(o, "TFA1 ID %04x %+.1f %i%% seq %x lowbat %i RSSI %i\n", id, temp, hum, seq, batfail, rssi);
+			emit_data(o, d, T_TFA_1, (uint64_t)id, temp, hum, seq, batfail, rssi);
+		}
+	}
+	d->sr_cnt = -1;
+	d->byte_cnt = 0;
+	r[10] = 0x00;
+}
+
+/* tfa2.cpp:219-279 */
+static void tfa2_flush_tfa(orc_t *o, dec_t *d, int rssi, int offset)
+{
+	uint8_t *r = d->rdata;
+	if (d->byte_cnt >= 7) {
+		int id = (d->type << 28) | (r[2] << 8) | (r[3] & 0xc0);
+		double temp = ((r[3] & 0xf) * 100 + (r[4] >> 4) * 10 + (r[4] & 0xf));
+		temp = temp * 0.1 - 40;
+		int hum = r[5];
+		uint8_t crc_val = r[6];
+		uint8_t crc_calc = orc_crc8(&r[2], 4);
+		if (hum == 0x7d)
+			id |= 1;
+		if (crc_val == crc_calc) {
+			if (hum > 100)
+				hum = 0;
+			TXT(o, "TFA%i ID %06x %+.1lf %i%% RSSI %i Offset %.0lfkHz\n", d->type + 1, id, temp, hum, rssi,
+			    -1536.0 * offset / 131072);
+			emit_data(o, d, d->type, (uint64_t)(int64_t)id, temp, hum, 0, 0, rssi);
+		}
+	}
+	d->sr_cnt = -1;
+	d->sr = 0;
+	d->byte_cnt = 0;
+}
+
+/* tfa2.cpp:72-217 */
+static void tfa2_flush_tx22(orc_t *o, dec_t *d, int rssi, int offset)
+{
+	uint8_t *r = d->rdata;
+	if (d->byte_cnt >= 7 && d->byte_cnt < 64 && (r[2] >> 4) == 0xa) {
+		int id = ((r[2] & 0xf) << 2) | (r[3] >> 6);
+		int error = !((r[3] >> 4) & 1);
+		int lowbat = (r[3] >> 3) & 1;
+		int num = r[3] & 7;
+		uint8_t crc_val = r[2 * num + 4];
+		uint8_t crc_calc = orc_crc8(&r[2], 2 + 2 * num);
+		if (crc_val == crc_calc && num <= 8) {
+			int have_temp = 0, have_hum = 0, have_rain = 0, have_wind = 0, have_gust = 0;
+			double temp = 0, hum = 0, rain = 0, wdir = 0, wspeed = 0, wgust = 0;
+			for (int n = 0; n < num; n++) {
+				const uint8_t *w = &r[4 + n * 2];
+				switch (w[0] >> 4) {
+				case 0: {
+					double v = (w[0] & 0xf) * 100 + (w[1] >> 4) * 10 + (w[1] & 0xf);
+					temp = (v * 0.1) - 40;
+					have_temp = 1;
+					break;
+				}
+				case 1:
+					hum = (w[0] & 0xf) * 100 + (w[1] >> 4) * 10 + (w[1] & 0xf);
+					have_hum = 1;
+					break;
+				case 2:
+					rain = ((w[0] & 0xf) << 8) + w[1];
+					have_rain = 1;
+					break;
+				case 3:
+					wdir = (w[0] & 0xf) * 22.5;
+					wspeed = w[1] * 0.1;
+					have_wind = 1;
+					break;
+				case 4:
+					wgust = (((w[0] & 0xf) << 8) + w[1]) * 0.1;
+					have_gust = 1;
+					break;
+				default:
+					break;
+				}
+			}
+			int alarm = error | lowbat;
+			int new_id = (d->type << 28) | (id << 4);
+			TXT(o, "TX22 ID %x, ", new_id);
+			if (have_temp)
+				TXT(o, "temp %g, ", temp);
+			if (have_hum)
+				TXT(o, "hum %g, ", hum);
+			if (have_rain)
+				TXT(o, "rain %g, ", rain);
+			if (have_wind)
+				TXT(o, "speed %g, dir %g, ", wspeed, wdir);
+			if (have_gust)
+				TXT(o, "gust %g, ", wgust);
+			TXT(o, "RSSI %i, offset %.0lfkHz\n", rssi, -1536.0 * offset / 131072);
+			if (have_temp)
+				emit_data(o, d, d->type, (uint64_t)(int64_t)new_id, temp, hum, 0, alarm, rssi);
+			if (have_rain)
+				emit_data(o, d, d->type, (uint64_t)(int64_t)(new_id | 2), rain, 0, 0, alarm, rssi);
+			if (have_wind)
+				emit_data(o, d, d->type, (uint64_t)(int64_t)(new_id | 3), wspeed, wdir, 0, alarm, rssi);
+			if (have_gust)
+				emit_data(o, d, d->type, (uint64_t)(int64_t)(new_id | 4), wgust, 0, 0, alarm, rssi);
+		}
+	}
+	d->sr_cnt = -1;
+	d->sr = 0;
+	d->byte_cnt = 0;
+}
+
+/* ---- WHB payload parsers (whb.cpp:109-475) */
+
+#define BE16(x) (((x)[0] << 8) | (x)[1])
+#define BE24(x) (((x)[0] << 16) | ((x)[1] << 8) | (x)[2])
+#define BE32(x) (((uint32_t)(x)[0] << 24) | ((x)[1] << 16) | ((x)[2] << 8) | (x)[3])
+
+static const uint32_t timeunit_tab[4] = { 24 * 60 * 60, 60 * 60, 60, 1 }; /* whb.cpp:65-70 */
+
+static double cvt_temp(uint16_t raw, int extended)
+{
+	if (extended == 1)
+		return (raw & 0x800) ? -((raw ^ 0xfff) + 1) * 0.1 : raw * 0.1;
+	return (raw & 0x400) ? -((raw ^ 0x7ff) + 1) * 0.1 : raw * 0.1;
+}
+
+/* crc_initvals, whb.cpp:50-62; 0 = unsupported type */
+static int whb_crc_init(uint32_t stype, uint32_t *init)
+{
+	switch (stype) {
+	case 0x02: *init = 0x97d97a26; return 1;
+	case 0x03: *init = 0xf59c5a1e; return 1;
+	case 0x04: *init = 0x98e1d11f; return 1;
+	case 0x06: *init = 0xa7a41254; return 1;
+	case 0x07: *init = 0x3303fb1d; return 1;
+	case 0x08: *init = 0x29f0f49b; return 1;
+	case 0x09: *init = 0xa7a41254; return 1;
+	case 0x0b: *init = 0xe7720ae4; return 1;
+	case 0x10: *init = 0x62d0afc1; return 1;
+	case 0x11: *init = 0x8cba0708; return 1;
+	case 0x12: *init = 0x5a9e30ae; return 1;
+	default: return 0;
+	}
+}
+
+static void whb_payload(orc_t *o, dec_t *d, uint32_t stype, const uint8_t *msg, uint64_t id, int rssi)
+{
+	const int T = T_TFA_WHB;
+	uint16_t seq = BE16(msg) & 0x3fff;
+	switch (stype) {
+	case 0x02: { /* whb.cpp:126-148 */
+		uint16_t temp = BE16(msg + 2) & 0x7ff, ptemp = BE16(msg + 4) & 0x7ff;
+		TXT(o, "WHB02 ID %llx TEMP %g, PTEMP %g\n", (unsigned long long)id, cvt_temp(temp, 0), cvt_temp(ptemp, 0));
+		emit_data(o, d, T, id << 4, cvt_temp(temp, 0), 0, seq, 0, rssi);
+		break;
+	}
+	case 0x03: { /* whb.cpp:151-177 */
+		uint16_t temp = BE16(msg + 2) & 0x7ff, hum = BE16(msg + 4) & 0xff;
+		uint16_t ptemp = BE16(msg + 6) & 0x7ff, phum = BE16(msg + 8) & 0xff;
+		TXT(o, "WHB03 ID %llx TEMP %g HUM %i, PTEMP %g PHUM %i\n", (unsigned long long)id, cvt_temp(temp, 0), hum,
+		    cvt_temp(ptemp, 0), phum);
+		emit_data(o, d, T, id << 4, cvt_temp(temp, 0), hum, seq, 0, rssi);
+		break;
+	}
+	case 0x04: { /* whb.cpp:180-213 */
+		uint16_t temp = BE16(msg + 2) & 0x7ff, hum = BE16(msg + 4) & 0xff;
+		uint8_t wet = msg[6];
+		uint16_t ptemp = BE16(msg + 7) & 0x7ff, phum = BE16(msg + 9) & 0xff, pwet = msg[11];
+		TXT(o, "WHB04 ID %llx TEMP %g HUM %i WET %i, PTEMP %g PHUM %i PWET %i\n", (unsigned long long)id,
+		    cvt_temp(temp, 0), hum, (wet & 1) ^ 1, cvt_temp(ptemp, 0), phum, (pwet & 1) ^ 1);
+		emit_data(o, d, T, id << 4, cvt_temp(temp, 0), hum, seq, 0, rssi);
+		emit_data(o, d, T, (id << 4) | 5, (wet & 1) ^ 1, 0, seq, 0, rssi);
+		break;
+	}
+	case 0x06:
+	case 0x09: { /* whb.cpp:217-258 */
+		int ext = (stype == 0x09);
+		uint16_t temp = BE16(msg + 2) & 0x7ff;
+		uint16_t temp2 = BE16(msg + 4) & (ext ? 0xfff : 0x7ff);
+		uint16_t ptemp2 = BE16(msg + 10) & (ext ? 0xfff : 0x7ff);
+		uint16_t hum = BE16(msg + 6) & 0xff, ptemp = BE16(msg + 8) & 0x7ff, phum = BE16(msg + 12) & 0xff;
+		TXT(o, "WHB0%i ID %llxTEMP %g HUM %i TEMP2 %g, PTEMP %g PHUM %i PTEMP2 %g\n", ext ? 9 : 6,
+		    (unsigned long long)id, cvt_temp(temp, 0), hum, cvt_temp(temp2, ext), cvt_temp(ptemp, 0), phum,
+		    cvt_temp(ptemp2, ext));
+		emit_data(o, d, T, id << 4, cvt_temp(temp, 0), hum, seq, 0, rssi);
+		emit_data(o, d, T, (id << 4) | 1, cvt_temp(temp2, ext), 0, seq, 0, rssi);
+		break;
+	}
+	case 0x07: { /* whb.cpp:261-295 */
+		uint16_t temp[4], hum[4];
+		for (int n = 0; n < 4; n++) {
+			temp[n] = BE16(msg + 2 + 4 * n) & 0x07ff;
+			hum[n] = BE16(msg + 4 + 4 * n) & 0x0ff;
+		}
+		TXT(o, "WHB07 ID %llx TEMP_IN %g HUM_IN %i TEMP_OUT %g HUM_OUT %i\n", (unsigned long long)id,
+		    cvt_temp(temp[0], 0), hum[0], cvt_temp(temp[1], 0), hum[1]);
+		emit_data(o, d, T, id << 4, cvt_temp(temp[0], 0), hum[0], seq, 0, rssi);
+		emit_data(o, d, T, (id << 4) | 0xc, cvt_temp(temp[1], 0), hum[1], seq, 0, rssi);
+		break;
+	}
+	case 0x08: { /* whb.cpp:298-334 */
+		uint16_t temp = BE16(msg + 2) & 0x07ff;
+		uint16_t cnt = BE16(msg + 4);
+		uint16_t x1 = BE16(msg + 6 + 2);
+		uint32_t t1 = timeunit_tab[(x1 >> 14) & 3] * (x1 & 0x3fff);
+		TXT(o, "WHB08 ID %llx cnt %i\n", (unsigned long long)id, cnt);
+		emit_data(o, d, T, (id << 4) | 2, cnt, t1, seq, 0, rssi);
+		emit_data(o, d, T, id << 4, cvt_temp(temp, 0), 0, seq, 0, rssi);
+		break;
+	}
+	case 0x0b: { /* whb.cpp:337-372; note float storage of dir/speed/gust and the 24-bit sequence */
+		uint32_t seq24 = BE24(msg);
+		uint32_t v = BE32(msg + 3);
+		float dir = 22.5 * (v >> 28);
+		float speed = (((v >> 16) & 0xff) + 256 * ((v >> 25) & 1)) * 0.1;
+		float gust = (((v >> 8) & 0xff) + 256 * ((v >> 24) & 1)) * 0.1;
+		uint32_t tm = (v & 0xff) * 2;
+		TXT(o, "WHB0b ID %llx #%i DIR %f SPEED %f GUST %f time %i\n", (unsigned long long)id, 0, dir, speed, gust,
+		    tm);
+		emit_data(o, d, T, (id << 4) | 3, speed, dir, (int)seq24, 0, rssi);
+		emit_data(o, d, T, (id << 4) | 4, gust, 0, (int)seq24, 0, rssi);
+		break;
+	}
+	case 0x10: { /* whb.cpp:375-402 */
+		uint16_t x0 = BE16(msg + 2), x1 = BE16(msg + 4);
+		int state0 = x0 >> 15;
+		uint32_t t0 = timeunit_tab[(x0 >> 13) & 3] * (x0 & 0x1fff);
+		uint32_t t1 = timeunit_tab[(x1 >> 13) & 3] * (x1 & 0x1fff);
+		TXT(o, "WHB10 ID %llx #%i %i %i\n", (unsigned long long)id, 0, state0, t0);
+		emit_data(o, d, T, (id << 4) | 5, state0, t1, seq, 0, rssi);
+		break;
+	}
+	case 0x11: { /* whb.cpp:405-441 */
+		uint16_t temp[8], hum[8];
+		for (int n = 0; n < 8; n++) {
+			temp[n] = BE16(msg + 2 + 4 * n) & 0x07ff;
+			hum[n] = BE16(msg + 4 + 4 * n) & 0xff;
+		}
+		TXT(o, "WHB11 %llx TEMP1 %g HUM1 %i TEMP2 %g HUM2 %i TEMP3 %g HUM3 %i TEMP_IN %g HUM_IN %i\n",
+		    (unsigned long long)id, cvt_temp(temp[0], 0), hum[0], cvt_temp(temp[1], 0), hum[1], cvt_temp(temp[2], 0),
+		    hum[2], cvt_temp(temp[3], 0), hum[3]);
+		emit_data(o, d, T, id << 4, cvt_temp(temp[3], 0), hum[3], seq, 0, rssi);
+		for (int n = 0; n < 3; n++)
+			emit_data(o, d, T, (id << 4) | (0xc + n), cvt_temp(temp[n], 0), hum[n], seq, 0, rssi);
+		break;
+	}
+	case 0x12: { /* whb.cpp:444-475 */
+		uint16_t hum[5] = { (uint16_t)(msg[8] & 0x7f), (uint16_t)(msg[2] & 0x7f), (uint16_t)(msg[3] & 0x7f),
+				    (uint16_t)(msg[4] & 0x7f), (uint16_t)(msg[5] & 0x7f) };
+		uint16_t temp = BE16(msg + 6) & 0x7ff;
+		TXT(o, "WHB12 %llx TEMP %g HUM %i HUM3h %i HUM24h %i HUM7d %i HUM30d %i\n", (unsigned long long)id,
+		    cvt_temp(temp, 0), hum[0], hum[1], hum[2], hum[3], hum[4]);
+		emit_data(o, d, T, id << 4, cvt_temp(temp, 0), hum[0], seq, 0, rssi);
+		emit_data(o, d, T, (id << 4) + 1, 0, hum[1], seq, 0, rssi);
+		for (int n = 0; n < 3; n++)
+			emit_data(o, d, T, (id << 4) + 0xc + n, 0, hum[2 + n], seq, 0, rssi);
+		break;
+	}
+	}
+}
+
+/* whb.cpp:477-564 */
+static void whb_flush(orc_t *o, dec_t *d, int rssi)
+{
+	uint8_t *r = d->rdata;
+	if (!(d->byte_cnt < 11 || d->byte_cnt > 60)) {
+		int plen = r[4];
+		if (plen <= 60) {
+			uint32_t stype = r[5], init;
+			if (!whb_crc_init(stype, &init)) {
+				TXT(o, "WHB: Probably unsupported sensor type %02x! Please report\n", stype);
+			} else {
+				/* plen<4 makes the reference call calc() with a negative length: the loop does not run */
+				uint32_t crc_calc = orc_crc32(&r[4], plen - 4, init);
+				uint32_t crc_val = BE32(&r[plen]);
+				if (crc_calc == crc_val) {
+					uint64_t id = 0;
+					for (int n = 0; n < 6; n++)
+						id = (id << 8) | r[5 + n];
+					whb_payload(o, d, stype, &r[11], id, rssi);
+				}
+			}
+		}
+	}
+	d->sr_cnt = -1;
+	d->sr = 0;
+	d->byte_cnt = 0;
+	d->synced = 0;
+}
+
+static void dem_store_bit(orc_t *o, dem_t *m, int bit)
+{
+	if (m->kind == 0)
+		tfa1_store_bit(o, &m->dec, bit);
+	else if (m->kind == 1)
+		tfa2_store_bit(o, &m->dec, bit);
+	else
+		whb_store_bit(o, &m->dec, bit);
+}
+
+static void dem_flush(orc_t *o, dem_t *m, int rssi_db, int offset, int64_t rssi_raw)
+{
+	log_event(o, &m->dec, rssi_db, offset, rssi_raw);
+	if (m->kind == 0)
+		tfa1_flush(o, &m->dec, rssi_db);
+	else if (m->kind == 1) {
+		if (m->dec.type == T_TX22)
+			tfa2_flush_tx22(o, &m->dec, rssi_db, offset);
+		else
+			tfa2_flush_tfa(o, &m->dec, rssi_db, offset);
+	} else
+		whb_flush(o, &m->dec, rssi_db);
+}
+
+/* ---------------------------------------------------------------- demod steps */
+
+/* tfa1.cpp:143-190 (BITPERIOD = 10, tfa1.cpp:34) */
+static int tfa1_demod(orc_t *o, dem_t *m, int thresh, int pwr, int index, int I, int Q)
+{
+	int triggered = 0;
+	if (pwr > thresh)
+		m->timeout_cnt = 400;
+	if (m->timeout_cnt) {
+		triggered++;
+		int dev = orc_fm_dev_nrzs(I, Q, m->last_i, m->last_q);
+		if (dev > m->mark_lvl)
+			m->mark_lvl = dev;
+		else
+			m->mark_lvl = d2i(m->mark_lvl * 0.95);
+		if (m->mark_lvl > m->rssi_i)
+			m->rssi_i = m->mark_lvl;
+		m->timeout_cnt--;
+		if (dev < m->mark_lvl / 2) {
+			if (m->last_bit_idx) {
+				if (index - m->last_bit_idx > 4) {
+					for (int n = 22; n <= (index - m->last_bit_idx); n += 20)
+						dem_store_bit(o, m, 1);
+					dem_store_bit(o, m, 0);
+				}
+			}
+			if (index - m->last_bit_idx > 2)
+				m->last_bit_idx = index;
+		}
+		if (!m->timeout_cnt) {
+			dem_flush(o, m, d2i(10 * log10((double)m->rssi_i)), 0, m->rssi_i);
+			m->mark_lvl = 0;
+			m->rssi_i = 0;
+			m->last_bit_idx = 0;
+		}
+	}
+	m->last_i = I;
+	m->last_q = Q;
+	return triggered;
+}
+
+/* tfa2.cpp:325-334 */
+static void tfa2_reset(dem_t *m)
+{
+	m->offset = 0;
+	m->bitcnt = 0;
+	m->dmin = 32767;
+	m->dmax = -32767;
+	m->last_bit = 0;
+	m->rssi_i = 0;
+	m->est_spb = m->spb;
+}
+
+/* tfa2.cpp:346-442 */
+static int tfa2_demod(orc_t *o, dem_t *m, int thresh, int pwr, int index, int I, int Q)
+{
+	int triggered = 0;
+	if (pwr > thresh) {
+		if (!m->timeout_cnt)
+			tfa2_reset(m);
+		m->timeout_cnt = d2i(16 * m->spb);
+	}
+	if (m->timeout_cnt) {
+		triggered++;
+		int dev = orc_fm_dev(I, Q, m->last_i, m->last_q);
+		int ld = d2i(iir_step(&m->iir, dev));
+		if (m->bitcnt < 10) {
+			if (ld > m->dmax)
+				m->dmax = (7 * m->dmax + ld) / 8;
+			if (ld < m->dmin)
+				m->dmin = (7 * m->dmin + ld) / 8;
+			m->offset = (m->dmax + m->dmin) / 2;
+			if (m->bitcnt > 4) {
+				/* int32 arithmetic that wraps in the reference binary */
+				uint32_t t = (uint32_t)m->rssi_i + (uint32_t)(I * I) + (uint32_t)(Q * Q);
+				m->rssi_i = (int32_t)((uint32_t)m->rssi_i + (uint32_t)((int32_t)t / 100));
+			}
+		}
+		m->timeout_cnt--;
+		dev = ld;
+		int noffset = d2i(0.9 * m->offset);
+		int bit = 0;
+		const int margin = 32;
+		if (dev > noffset + (m->dmax / margin))
+			bit = 1;
+		if ((dev > noffset + m->dmax / margin || dev < noffset + m->dmin / margin) && bit != m->last_bit) {
+			if (index > (m->last_bit_idx + 8)) {
+				m->bitcnt++;
+				int tdiff = index - m->last_bit_idx;
+				if (tdiff > m->spb / 4 && tdiff < 32 * m->spb) {
+					int bit_diff = (index - m->last_bit_idx) / 2;
+					int numbits = d2i((bit_diff + (m->est_spb / 2)) / m->est_spb);
+					if (numbits < 32)
+						for (int n = 1; n < numbits; n++)
+							dem_store_bit(o, m, m->last_bit);
+					dem_store_bit(o, m, bit);
+					m->last_bit = bit;
+				}
+			}
+			if (index - m->last_bit_idx > 2)
+				m->last_bit_idx = index;
+		}
+		if (!m->timeout_cnt) {
+			for (int n = 0; n < 16; n++)
+				dem_store_bit(o, m, m->last_bit);
+			dem_flush(o, m, d2i(10 * log10((double)m->rssi_i)), m->offset, m->rssi_i);
+			tfa2_reset(m);
+		}
+	}
+	m->last_i = I;
+	m->last_q = Q;
+	return triggered;
+}
+
+/* whb.cpp:616-623 */
+static void whb_reset(dem_t *m)
+{
+	m->offset = 0;
+	m->bitcnt = 0;
+	m->rssi_d = 0;
+	m->step = m->last_peak = 0;
+}
+
+/* whb.cpp:632-707 */
+static int whb_demod(orc_t *o, dem_t *m, int thresh, int pwr, int index, int I, int Q)
+{
+	(void)index;
+	int triggered = 0;
+	if (pwr > thresh) {
+		if (!m->timeout_cnt)
+			whb_reset(m);
+		m->timeout_cnt = d2i(8 * m->spb);
+	}
+	if (m->timeout_cnt) {
+		triggered++;
+		int dev = orc_fm_dev_nrzs(I, Q, m->last_i, m->last_q);
+		dev = d2i(iir_step(&m->iir, dev));
+		if (!m->dec.synced)
+			m->avg_of = d2i(iir_step(&m->iir_avg, 0.5 * dev));
+		m->timeout_cnt--;
+		int tdiff = (int)(m->step - m->last_peak);
+		if (dev < m->avg_of && dev > m->last_dev && (tdiff > 3 * m->spb / 4)) {
+			dem_store_bit(o, m, 0);
+			m->bitcnt++;
+			int bit0 = d2i((tdiff + m->spb / 2) / m->spb);
+			for (int n = 1; n < bit0; n++) {
+				dem_store_bit(o, m, 1);
+				m->bitcnt++;
+			}
+			m->last_peak = m->step;
+		}
+		m->last_dev = dev;
+		if (m->dec.synced)
+			m->rssi_d += (I * I + Q * Q);
+		if (!m->timeout_cnt) {
+			if (m->dec.synced) {
+				for (int n = 0; n < 16; n++)
+					dem_store_bit(o, m, 0);
+				dem_flush(o, m, d2i(10 * log10(m->rssi_d * 0.00025 + 1.0)), m->offset, (int64_t)m->rssi_d);
+			}
+			whb_reset(m);
+			m->rssi_d = 0;
+		}
+	}
+	m->last_i = I;
+	m->last_q = Q;
+	m->step++;
+	return triggered;
+}
+
+/* ---------------------------------------------------------------- engine */
+
+orc_t *orc_create(int types_mask, int thresh, int wide)
+{
+	build_tabs();
+	orc_t *o = (orc_t *)calloc(1, sizeof(orc_t));
+	o->wide = wide;
+	/* fm_demod.cpp:18-32 */
+	o->thresh = thresh;
+	o->thresh_mode = 0;
+	if (thresh == 0) {
+		o->thresh = 500;
+		o->thresh_mode = 1;
+	}
+	/* registration, main.cpp:173-218 */
+	static const struct {
+		int type, kind;
+		double baud;
+	} reg[ORC_NSLOTS] = { { T_TFA_1, 0, 0 }, { T_TFA_2, 1, 17240 }, { T_TFA_3, 1, 9600 }, { T_TX22, 1, 8842 },
+			      { T_TFA_WHB, 2, 6000 } };
+	for (int s = 0; s < ORC_NSLOTS; s++) {
+		if (!(types_mask & (1 << reg[s].type)))
+			continue;
+		dem_t *m = &o->dem[o->ndem++];
+		memset(m, 0, sizeof(*m));
+		m->kind = reg[s].kind;
+		dec_init(&m->dec, s, reg[s].type);
+		if (m->kind == 1) {
+			m->spb = (1536000 / 4.0) / reg[s].baud;
+			tfa2_reset(m);
+			iir_init(&m->iir, 0.5 / m->spb); /* tfa2.cpp:321, iir_fac 0.5 */
+		} else if (m->kind == 2) {
+			m->spb = (1536000 / 4.0) / reg[s].baud;
+			whb_reset(m);
+			iir_init(&m->iir, 2.0 / m->spb);        /* whb.cpp:610 */
+			iir_init(&m->iir_avg, 0.0025 / m->spb); /* whb.cpp:611 */
+		}
+	}
+	return o;
+}
+
+void orc_destroy(orc_t *o)
+{
+	if (!o)
+		return;
+	for (int n = 0; n < o->ndem; n++)
+		free(o->dem[n].dec.bits);
+	free(o->ev);
+	free(o->data);
+	free(o->text.p);
+	free(o->bitstext.p);
+	free(o->dec);
+	free(o);
+}
+
+void orc_set_log_bits(orc_t *o, int on) { o->log_bits = on; }
+void orc_set_keep_dec(orc_t *o, int on) { o->keep_dec = on; }
+void orc_set_quiet(orc_t *o, int on) { o->quiet = on; }
+
+/* fm_demod.cpp:34-74 */
+static void fsk_process(orc_t *o, const int16_t *d, int len)
+{
+	int triggered = 0;
+	o->runs++;
+	for (int n = 0; n < o->ndem; n++) /* decoder.cpp:118-122 */
+		if (o->dem[n].last_bit_idx)
+			o->dem[n].last_bit_idx -= len;
+	for (int i = 0; i < len; i += 2) {
+		int I = d[i], Q = d[i + 1];
+		int pwr = abs(I) + abs(Q);
+		int t = 0;
+		o->cur_index = i;
+		for (int n = 0; n < o->ndem; n++) {
+			dem_t *m = &o->dem[n];
+			if (m->kind == 0)
+				t += tfa1_demod(o, m, o->thresh, pwr, i, I, Q);
+			else if (m->kind == 1)
+				t += tfa2_demod(o, m, o->thresh, pwr, i, I, Q);
+			else
+				t += whb_demod(o, m, o->thresh, pwr, i, I, Q);
+		}
+		if (t)
+			triggered++;
+	}
+	o->triggered_avg = (31 * o->triggered_avg + triggered) / 32;
+	if (o->thresh_mode == 1 && (o->runs & 3) == 0) {
+		if (o->triggered_avg >= len / 32)
+			o->thresh += 2;
+		else if (o->triggered_avg <= len / 64 && o->thresh > 50)
+			o->thresh -= 2;
+	}
+}
+
+long orc_process(orc_t *o, const uint8_t *iq, size_t nbytes)
+{
+	static const int NB = ORC_BLOCK_BYTES;
+	int16_t *x = (int16_t *)malloc(NB * sizeof(int16_t));
+	int16_t *y = (int16_t *)malloc(2 * ORC_BLOCK_DEC * sizeof(int16_t));
+	const int16_t *t2 = o->wide ? taps_s2_wide : taps_s2_narrow;
+	long blocks = 0;
+	for (size_t pos = 0; pos + NB <= nbytes; pos += NB) {
+		for (int n = 0; n < NB; n++)
+			x[n] = (int16_t)(((int)iq[pos + n] - 128) << 6);
+		decimate_channel(&o->hi, x, NB / 2, t2, y);
+		decimate_channel(&o->hq, x + 1, NB / 2, t2, y + 1);
+		if (o->keep_dec && !o->quiet) {
+			if (o->ndec + 2 * ORC_BLOCK_DEC > o->capdec) {
+				o->capdec = (o->capdec + 2 * ORC_BLOCK_DEC) * 2;
+				o->dec = (int16_t *)realloc(o->dec, o->capdec * sizeof(int16_t));
+			}
+			memcpy(o->dec + o->ndec, y, 2 * ORC_BLOCK_DEC * sizeof(int16_t));
+			o->ndec += 2 * ORC_BLOCK_DEC;
+		}
+		fsk_process(o, y, 2 * ORC_BLOCK_DEC);
+		o->block++;
+		blocks++;
+	}
+	free(x);
+	free(y);
+	return blocks;
+}
+
+/* main.cpp:45-49 with decoder::store_bytes (decoder.cpp:35-40) */
+void orc_hex(orc_t *o, const uint8_t *bytes, int len)
+{
+	for (int n = 0; n < o->ndem; n++) {
+		dem_t *m = &o->dem[n];
+		if (len > 256)
+			len = 256;
+		memcpy(m->dec.rdata, bytes, len);
+		m->dec.byte_cnt = len;
+		m->dec.synced = 1;
+		dem_flush(o, m, 0, 0, 0);
+	}
+}
+
+size_t orc_num_events(const orc_t *o) { return o->nev; }
+const orc_event_t *orc_events(const orc_t *o) { return o->ev; }
+size_t orc_num_data(const orc_t *o) { return o->ndata; }
+const orc_data_t *orc_data(const orc_t *o) { return o->data; }
+const char *orc_text(const orc_t *o) { return o->text.p ? o->text.p : ""; }
+size_t orc_text_len(const orc_t *o) { return o->text.len; }
+size_t orc_num_dec(const orc_t *o) { return o->ndec; }
+const int16_t *orc_dec(const orc_t *o) { return o->dec; }
+const char *orc_bits_text(const orc_t *o) { return o->bitstext.p ? o->bitstext.p : ""; }
+int orc_thresh(const orc_t *o) { return o->thresh; }
+uint64_t orc_atan_uncertain(const orc_t *o)
+{
+	(void)o;
+	return g_uncertain;
+}
+
+void orc_clear_logs(orc_t *o)
+{
+	o->nev = 0;
+	o->ndata = 0;
+	o->text.len = 0;
+	if (o->text.p)
+		o->text.p[0] = 0;
+	o->bitstext.len = 0;
+	if (o->bitstext.p)
+		o->bitstext.p[0] = 0;
+	o->ndec = 0;
+}
