@@ -1,0 +1,133 @@
+/* include/tfrec_amd.h -- C ABI of the MI355X-native IQ->telegram hot path.
+ *
+ * This is the drop-in boundary for baycom/tfrec's inner loop.  In the reference one receiver does, per
+ * 65536-byte block of raw 8-bit IQ (engine.cpp:63-93):
+ *
+ *     datab[n] = (buf[n]-128)<<6;                      engine.cpp:77-78
+ *     ld = dc.process_iq(data, len, filter_type);      engine.cpp:85   (dsp_stuff.cpp:243-264)
+ *     fsk->process(data, ld);                          engine.cpp:86   (fm_demod.cpp:34-74)
+ *         -> demodulator::start / ::demod              decoder.h:65-67 (tfa1.cpp:143, tfa2.cpp:346, whb.cpp:632)
+ *         -> decoder::store_bit ... decoder::flush     decoder.h:39-40 (tfa1.cpp:120/47, tfa2.cpp:281/64, whb.cpp:566/477)
+ *
+ * Here the same work is done for a BATCH of independent streams on one GPU: tfrec_amd_submit_*()
+ * replaces the three calls above for every stream of the batch, and tfrec_amd_drain_events() hands
+ * back, per (stream, demodulator slot) and in order, what each reference decoder would have held at
+ * the moment demodulator::demod() called decoder::flush(rssi, offset): byte_cnt, rdata[], the raw
+ * RSSI accumulator and the frequency offset.  A host adapter replays each event into an (unchanged)
+ * reference decoder object with decoder::store_bytes(ev.rdata, ev.byte_cnt) + decoder::flush(
+ * tfrec_amd_rssi_db(...), ev.offset) -- the reference's own "-X" test entry (main.cpp:45-49,
+ * decoder.cpp:35-40) -- see INTEGRATION.md.
+ *
+ * Plain C types only; caller-owned buffers; int return codes (0 = ok, <0 = TFREC_AMD_E_*); no
+ * exceptions cross this boundary.  One host thread per context; contexts are independent (one per GPU
+ * in a multi-GPU job: streams shard by index, no collective is involved).
+ */
+#ifndef TFREC_AMD_H
+#define TFREC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFREC_AMD_BLOCK_BYTES 65536 /* RLS, engine.cpp:68 */
+#define TFREC_AMD_BLOCK_DEC 8192    /* decimated IQ pairs per block (4:1, dsp_stuff.cpp:243-264) */
+#define TFREC_AMD_NSLOTS 5
+
+/* demodulator slots = registration order of main.cpp:173-218 */
+enum { TFREC_AMD_SLOT_TFA1 = 0, TFREC_AMD_SLOT_TFA2 = 1, TFREC_AMD_SLOT_TFA3 = 2, TFREC_AMD_SLOT_TX22 = 3,
+       TFREC_AMD_SLOT_WHB = 4 };
+
+/* error codes */
+enum {
+	TFREC_AMD_OK = 0,
+	TFREC_AMD_E_INVAL = -1,     /* bad argument / unsupported configuration */
+	TFREC_AMD_E_NOMEM = -2,     /* host or device allocation failed */
+	TFREC_AMD_E_HIP = -3,       /* a HIP runtime call failed (no device, launch failure, ...) */
+	TFREC_AMD_E_OVERFLOW = -4,  /* event buffer too small: events were dropped */
+	TFREC_AMD_E_STATE = -5      /* call sequence error */
+};
+
+/* config.flags */
+#define TFREC_AMD_F_ALL_FLUSHES 1u /* emit an event for EVERY decoder::flush call (parity/debug mode); default:
+				      only flushes whose byte_cnt reaches the decoder's minimum length
+				      (tfa1.cpp:49, tfa2.cpp:76/222, whb.cpp:484) */
+#define TFREC_AMD_F_TIMING 2u      /* record HIP events around every kernel (tfrec_amd_get_timings) */
+
+typedef struct {
+	int32_t n_streams;   /* independent IQ streams in the batch (>=1) */
+	int32_t types_mask;  /* bit n = sensor_e n as main.cpp -T: TFA_1 0x01, TFA_2 0x02, TFA_3 0x04, TX22 0x08, WHB 0x20 */
+	int32_t thresh;      /* trigger threshold, main.cpp -t (fixed; the reference's auto mode 0 is not offered yet) */
+	int32_t filter_type; /* 0 = narrow, 1 = wide (-W), dsp_stuff.cpp:176-178 */
+	int32_t device;      /* HIP device ordinal */
+	int32_t max_blocks;  /* largest n_blocks a submit may carry (sizes the device buffers) */
+	int32_t max_events;  /* device event buffer capacity per submit/drain cycle */
+	uint32_t flags;      /* TFREC_AMD_F_* */
+} tfrec_amd_config;
+
+/* One decoder::flush() call site (tfa1.cpp:180, tfa2.cpp:434, whb.cpp:696).  96 bytes. */
+typedef struct {
+	uint32_t stream;    /* stream index within the batch */
+	uint8_t slot;       /* TFREC_AMD_SLOT_* */
+	uint8_t status;     /* 1 = passes the decoder's CRC + sanity checks (a telegram), 2 = rejected, 0 = shorter than a telegram */
+	uint16_t byte_cnt;  /* decoder byte_cnt at flush (saturated at 65535) */
+	int32_t offset;     /* second flush() argument (tfa2.cpp:434; 0 for TFA_1 and WHB) */
+	uint32_t seq;       /* ordinal of this flush within (stream, slot) since context creation */
+	int64_t end_sample; /* decimated sample index (since stream start) at which flush fired */
+	int64_t rssi_raw;   /* raw RSSI accumulator: tfa1.cpp:161, tfa2.cpp:373, whb.cpp:678 (an exact integer) */
+	uint8_t rdata[64];  /* decoder rdata[0..64) at flush, before the decoder clears anything */
+} tfrec_amd_event;
+
+typedef struct tfrec_amd_ctx tfrec_amd_ctx;
+
+/* kernel timings of the last submit (TFREC_AMD_F_TIMING), milliseconds */
+typedef struct {
+	float frontend_ms; /* u8->s16 + 2-stage decimating FIR + trigger mask kernel */
+	float chains_ms;   /* demodulator/decoder chain kernel(s) */
+	float total_ms;    /* first kernel start to last kernel end */
+} tfrec_amd_timings;
+
+const char *tfrec_amd_version(void);
+const char *tfrec_amd_strerror(int code);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char *tfrec_amd_last_error(void);
+
+int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out);
+int tfrec_amd_destroy(tfrec_amd_ctx *ctx);
+
+/* Process n_blocks 65536-byte blocks of every stream.  Stream s starts at d_iq + s*stream_stride_bytes
+ * (device memory, u8 interleaved I,Q as the reference's -S dump files, sdr.cpp:233-234).  Asynchronous
+ * on hip_stream (a hipStream_t, NULL = default stream); all demodulator/decoder state carries over to
+ * the next submit exactly as it carries from block to block in the reference. */
+int tfrec_amd_submit_device(tfrec_amd_ctx *ctx, const void *d_iq, size_t stream_stride_bytes, int n_blocks,
+			    void *hip_stream);
+/* Same with host memory: stages the batch through an internal device buffer (H2D copy included). */
+int tfrec_amd_submit_host(tfrec_amd_ctx *ctx, const uint8_t *h_iq, size_t stream_stride_bytes, int n_blocks);
+
+/* Wait for submitted work. */
+int tfrec_amd_sync(tfrec_amd_ctx *ctx);
+
+/* Wait, then copy the events produced since the last drain to out[0..cap), ordered by
+ * (stream, slot, seq).  *n_out = number written.  Returns TFREC_AMD_E_OVERFLOW if the device buffer or
+ * cap was too small (the events that fit are still returned). */
+int tfrec_amd_drain_events(tfrec_amd_ctx *ctx, tfrec_amd_event *out, int cap, int *n_out);
+
+/* Number of events waiting (synchronises). */
+int tfrec_amd_pending_events(tfrec_amd_ctx *ctx, int *n);
+
+/* The dB value the reference demodulator passes to decoder::flush for this slot, computed with the
+ * reference's host expressions (tfa1.cpp:180, tfa2.cpp:434, whb.cpp:696) including (int)(10*log10(0)). */
+int tfrec_amd_rssi_db(int slot, int64_t rssi_raw);
+
+/* Parity/debug: copy the decimated int16 IQ of the last submit for one stream (n_pairs*2 int16). */
+int tfrec_amd_read_decimated(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_t n_pairs);
+/* Samples whose FM-discriminator truncation was closer than 1e-9 to an integer boundary. */
+int tfrec_amd_atan_uncertain(tfrec_amd_ctx *ctx, uint64_t *n);
+int tfrec_amd_get_timings(tfrec_amd_ctx *ctx, tfrec_amd_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,224 @@
+"""ctypes binding of the C ABI in include/tfrec_amd.h.
+
+The product is the HIP library ``libtfrec_amd.so``; this module only loads it, marshals arguments and
+exposes the events as numpy records.  There is NO CPU fallback: if the library is missing or no GPU is
+present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+BLOCK_BYTES = 65536
+BLOCK_DEC = 8192
+NSLOTS = 5
+SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
+
+F_ALL_FLUSHES = 1
+F_TIMING = 2
+
+E_OK, E_INVAL, E_NOMEM, E_HIP, E_OVERFLOW, E_STATE = 0, -1, -2, -3, -4, -5
+
+
+class TfrecAmdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("tfrec_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_streams", C.c_int32),
+        ("types_mask", C.c_int32),
+        ("thresh", C.c_int32),
+        ("filter_type", C.c_int32),
+        ("device", C.c_int32),
+        ("max_blocks", C.c_int32),
+        ("max_events", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Timings(C.Structure):
+    _fields_ = [("frontend_ms", C.c_float), ("chains_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+EVENT_DTYPE = np.dtype(
+    [
+        ("stream", "<u4"),
+        ("slot", "u1"),
+        ("status", "u1"),
+        ("byte_cnt", "<u2"),
+        ("offset", "<i4"),
+        ("seq", "<u4"),
+        ("end_sample", "<i8"),
+        ("rssi_raw", "<i8"),
+        ("rdata", "u1", (64,)),
+    ]
+)
+assert EVENT_DTYPE.itemsize == 96
+
+# every symbol include/tfrec_amd.h declares
+EXPORTS = (
+    "tfrec_amd_version", "tfrec_amd_strerror", "tfrec_amd_last_error", "tfrec_amd_create", "tfrec_amd_destroy",
+    "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
+    "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
+    "tfrec_amd_get_timings",
+)
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB_SO
+
+
+def load_library(build: bool = True):
+    """Load libtfrec_amd.so (building it in-tree first when hipcc is available).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build:
+        try:
+            _build.build_device_lib()
+        except (OSError, FileNotFoundError):
+            pass  # no hipcc on this box: use the prebuilt library that travelled with the tree
+    if not os.path.exists(_build.LIB_SO):
+        raise RuntimeError("HIP extension %s is missing: run __graft_entry__.build()" % _build.LIB_SO)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing torch first makes our
+    # library bind to that same copy (same SONAME) instead of loading /opt/rocm's next to it, which would
+    # leave whichever runtime comes second without a GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(_build.LIB_SO)
+    L.tfrec_amd_version.restype = C.c_char_p
+    L.tfrec_amd_strerror.restype = C.c_char_p
+    L.tfrec_amd_strerror.argtypes = [C.c_int]
+    L.tfrec_amd_last_error.restype = C.c_char_p
+    L.tfrec_amd_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.tfrec_amd_destroy.argtypes = [C.c_void_p]
+    L.tfrec_amd_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.tfrec_amd_submit_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.tfrec_amd_sync.argtypes = [C.c_void_p]
+    L.tfrec_amd_drain_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.tfrec_amd_pending_events.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.tfrec_amd_rssi_db.argtypes = [C.c_int, C.c_int64]
+    L.tfrec_amd_rssi_db.restype = C.c_int
+    L.tfrec_amd_read_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.tfrec_amd_atan_uncertain.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.tfrec_amd_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    _lib = L
+    return L
+
+
+def _check(L, rc: int, ok=(E_OK,)):
+    if rc not in ok:
+        detail = L.tfrec_amd_last_error().decode() if rc == E_HIP or rc == E_INVAL or rc == E_NOMEM else ""
+        raise TfrecAmdError(rc, L.tfrec_amd_strerror(rc).decode() + (" (" + detail + ")" if detail else ""))
+    return rc
+
+
+def rssi_db(slot: int, rssi_raw: int) -> int:
+    return int(load_library().tfrec_amd_rssi_db(int(slot), int(rssi_raw)))
+
+
+class Receiver:
+    """A batch of ``n_streams`` independent receivers on one GPU (one C-ABI context).
+
+    ``submit`` replaces, for every stream, the reference's per-block
+    ``process_iq`` + ``fsk_demod::process`` (engine.cpp:85-86); ``drain`` returns the decoder flush events.
+    """
+
+    def __init__(self, n_streams: int, types_mask: int = 0x2F, thresh: int = 500, filter_type: int = 0,
+                 device: int = 0, max_blocks: int = 48, max_events: int | None = None, all_flushes: bool = False,
+                 timing: bool = False):
+        self.L = load_library()
+        if max_events is None:
+            max_events = max(4096, n_streams * max_blocks * 4 * (8 if all_flushes else 2))
+        flags = (F_ALL_FLUSHES if all_flushes else 0) | (F_TIMING if timing else 0)
+        self.cfg = Config(n_streams, types_mask, thresh, filter_type, device, max_blocks, max_events, flags)
+        self.h = C.c_void_p()
+        _check(self.L, self.L.tfrec_amd_create(C.byref(self.cfg), C.byref(self.h)))
+        self.n_streams = n_streams
+        self.max_events = max_events
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.tfrec_amd_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def submit(self, iq, n_blocks: int | None = None, stream=None):
+        """iq: torch uint8 CUDA tensor [n_streams, n_bytes] (resident in HBM) or a numpy/host array."""
+        if isinstance(iq, np.ndarray):
+            a = np.ascontiguousarray(iq, dtype=np.uint8).reshape(self.n_streams, -1)
+            nb = a.shape[1] // BLOCK_BYTES if n_blocks is None else n_blocks
+            _check(self.L, self.L.tfrec_amd_submit_host(self.h, a.ctypes.data, a.strides[0], nb))
+            return nb
+        import torch
+
+        assert iq.is_cuda and iq.dtype == torch.uint8 and iq.dim() == 2 and iq.shape[0] == self.n_streams
+        assert iq.stride(1) == 1
+        nb = iq.shape[1] // BLOCK_BYTES if n_blocks is None else n_blocks
+        st = torch.cuda.current_stream(iq.device) if stream is None else stream
+        self._keep = iq  # keep the buffer alive until the next submit/drain
+        _check(self.L, self.L.tfrec_amd_submit_device(self.h, C.c_void_p(iq.data_ptr()), iq.stride(0), nb,
+                                                      C.c_void_p(st.cuda_stream)))
+        return nb
+
+    def sync(self):
+        _check(self.L, self.L.tfrec_amd_sync(self.h))
+
+    def drain(self, allow_overflow: bool = False) -> np.ndarray:
+        out = np.zeros(self.max_events, dtype=EVENT_DTYPE)
+        n = C.c_int(0)
+        rc = self.L.tfrec_amd_drain_events(self.h, out.ctypes.data, self.max_events, C.byref(n))
+        _check(self.L, rc, ok=(E_OK, E_OVERFLOW) if allow_overflow else (E_OK,))
+        return out[: n.value]
+
+    def decimated(self, stream: int, n_pairs: int) -> np.ndarray:
+        out = np.empty(2 * n_pairs, dtype=np.int16)
+        _check(self.L, self.L.tfrec_amd_read_decimated(self.h, stream, out.ctypes.data, n_pairs))
+        return out
+
+    def atan_uncertain(self) -> int:
+        n = C.c_uint64(0)
+        _check(self.L, self.L.tfrec_amd_atan_uncertain(self.h, C.byref(n)))
+        return int(n.value)
+
+    def timings(self) -> dict:
+        t = Timings()
+        _check(self.L, self.L.tfrec_amd_get_timings(self.h, C.byref(t)))
+        return dict(frontend_ms=t.frontend_ms, chains_ms=t.chains_ms, total_ms=t.total_ms)
+
+
+def event_tuples(events: np.ndarray, stream: int | None = None):
+    """Canonical comparable form (slot, end_sample, byte_cnt, rssi_db, offset, rdata) of flush events,
+    in per-(stream, slot) order -- the same tuple the oracle and the reference harness produce."""
+    L = load_library()
+    out = []
+    for e in events:
+        if stream is not None and int(e["stream"]) != stream:
+            continue
+        out.append((int(e["slot"]), int(e["end_sample"]), int(e["byte_cnt"]),
+                    int(L.tfrec_amd_rssi_db(int(e["slot"]), int(e["rssi_raw"]))), int(e["offset"]),
+                    bytes(e["rdata"])))
+    return out

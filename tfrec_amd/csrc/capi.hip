@@ -1,0 +1,425 @@
+// tfrec_amd/csrc/capi.hip -- C ABI (include/tfrec_amd.h): context, submit, drain.  No torch types.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "tfrec_dev.h"
+
+namespace tfrec {
+hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
+			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
+			   unsigned long long *mask, size_t mask_stride, int thresh, const FrontTaps &taps);
+hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+			 size_t mask_stride, int n_streams, int n_blocks, long long sample_base, const ChainLaunch &L,
+			 tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
+}  // namespace tfrec
+
+using namespace tfrec;
+
+static thread_local char g_err[256] = "";
+
+static int hip_fail(hipError_t e, const char *what)
+{
+	snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+	return TFREC_AMD_E_HIP;
+}
+#define HIPCHK(call)                                   \
+	do {                                           \
+		hipError_t e_ = (call);                \
+		if (e_ != hipSuccess)                  \
+			return hip_fail(e_, #call);    \
+	} while (0)
+
+struct tfrec_amd_ctx {
+	tfrec_amd_config cfg;
+	ChainLaunch launch;
+	FrontTaps taps;
+	uint32_t *d_dec = nullptr;
+	size_t dec_stride = 0;  // uint32 units
+	unsigned long long *d_mask = nullptr;
+	size_t mask_stride = 0;
+	uint8_t *d_tail[2] = { nullptr, nullptr };
+	int tail_sel = 0;
+	tfrec_amd_event *d_events = nullptr;
+	EventBuf *d_eb = nullptr;
+	uint8_t *d_stage = nullptr;
+	size_t stage_bytes = 0;
+	long long sample_base = 0;
+	int last_blocks = 0;
+	hipStream_t last_stream = nullptr;
+	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+	bool timed = false;
+	unsigned long long uncertain_total = 0;
+};
+
+// ---- biquad coefficients (iir2::set, dsp_stuff.cpp:36-45) in the arithmetic of the reference's normative
+// build (oracle/tfrec_oracle.c header).  The five cut-offs the reference ever instantiates
+// (main.cpp:186-217, tfa2.cpp:321, whb.cpp:610-611) come from a table of the exact values that build
+// produces, so they do not depend on this host's libm tan(); other cut-offs use the formula.
+static BiquadCoef biquad_coef(double cutoff)
+{
+	static const struct {
+		double cutoff, b0, a1, a2;
+	} known[] = {
+		{ 0.5 / (384000.0 / 17240), 0x1.27f98b1037a14p-8, 0x1.cd1527f4a26e2p+0, -0x1.a36a1c41c6995p-1 },
+		{ 0.5 / (384000.0 / 9600), 0x1.7ed02b18a270dp-10, 0x1.e397ac010fc89p+0, -0x1.ca2cf85850d62p-1 },
+		{ 0.5 / (384000.0 / 8842), 0x1.461fa1a309718p-10, 0x1.e5d4f47377e30p+0, -0x1.ce36282a35d90p-1 },
+		{ 2.0 / 64.0, 0x1.14a67102a1ffdp-7, 0x1.b949652fa3970p+0, -0x1.83dd316f714e0p-1 },
+		{ 0.0025 / 64.0, 0x1.02ae4cfc8910ap-26, 0x1.ffe9409fe171bp+0, -0x1.ffd283451f7d3p-1 },
+	};
+	BiquadCoef c;
+	for (const auto &k : known)
+		if (k.cutoff == cutoff) {
+			c.b0 = k.b0;
+			c.b1 = k.b0 + k.b0;
+			c.b2 = k.b0;
+			c.a1 = k.a1;
+			c.a2 = k.a2;
+			return c;
+		}
+	const double i = 1.0 / tan(cutoff * M_PI);
+	const double s = sqrt(2.0);
+	const double b0 = 1.0 / ((i + s) * i + 1.0);
+	const double t = i * i - 1.0;
+	c.b0 = b0;
+	c.b1 = b0 + b0;
+	c.b2 = b0;
+	c.a1 = (t + t) * b0;
+	c.a2 = ((s - i) * i - 1.0) * b0;
+	return c;
+}
+
+static int d2i_host(double v)
+{
+	if (!(v > -2147483649.0 && v < 2147483648.0))
+		return (int)0x80000000;
+	return (int)v;
+}
+
+extern "C" {
+
+const char *tfrec_amd_version(void) { return "tfrec_amd 0.1 (gfx950)"; }
+
+const char *tfrec_amd_strerror(int code)
+{
+	switch (code) {
+	case TFREC_AMD_OK: return "ok";
+	case TFREC_AMD_E_INVAL: return "invalid argument or unsupported configuration";
+	case TFREC_AMD_E_NOMEM: return "out of memory";
+	case TFREC_AMD_E_HIP: return "HIP runtime error";
+	case TFREC_AMD_E_OVERFLOW: return "event buffer overflow";
+	case TFREC_AMD_E_STATE: return "call sequence error";
+	default: return "unknown error";
+	}
+}
+
+const char *tfrec_amd_last_error(void) { return g_err; }
+
+int tfrec_amd_rssi_db(int slot, int64_t rssi_raw)
+{
+	if (slot == TFREC_AMD_SLOT_WHB)  // whb.cpp:696 as compiled: 10*log10(rssi*0.00025 + 1)
+		return d2i_host(10 * log10((double)rssi_raw * 0.00025 + 1.0));
+	// tfa1.cpp:180, tfa2.cpp:434: (int)(10*log10(rssi)) with an int rssi
+	return d2i_host(10 * log10((double)(int)rssi_raw));
+}
+
+int tfrec_amd_destroy(tfrec_amd_ctx *c)
+{
+	if (!c)
+		return TFREC_AMD_OK;
+	(void)hipSetDevice(c->cfg.device);
+	(void)hipDeviceSynchronize();
+	for (int a = 0; a < kNSlots; a++)
+		if (c->launch.states[a])
+			(void)hipFree(c->launch.states[a]);
+	(void)hipFree(c->d_dec);
+	(void)hipFree(c->d_mask);
+	(void)hipFree(c->d_tail[0]);
+	(void)hipFree(c->d_tail[1]);
+	(void)hipFree(c->d_events);
+	(void)hipFree(c->d_eb);
+	(void)hipFree(c->d_stage);
+	for (auto &e : c->ev)
+		if (e)
+			(void)hipEventDestroy(e);
+	delete c;
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
+{
+	if (!cfg || !out)
+		return TFREC_AMD_E_INVAL;
+	*out = nullptr;
+	if (cfg->n_streams < 1 || cfg->n_streams > 65535 || cfg->max_blocks < 1 || cfg->max_blocks > 4096 ||
+	    cfg->max_events < 1 || (cfg->types_mask & 0x2f) == 0 || (cfg->types_mask & ~0x2f) != 0 ||
+	    cfg->filter_type < 0 || cfg->filter_type > 1) {
+		snprintf(g_err, sizeof(g_err), "bad config");
+		return TFREC_AMD_E_INVAL;
+	}
+	if (cfg->thresh <= 0) {
+		// fm_demod.cpp:23-27 turns 0 into the adaptive mode; that per-block feedback loop is SURVEY 8(f2)
+		snprintf(g_err, sizeof(g_err), "thresh must be > 0 (auto threshold mode not available)");
+		return TFREC_AMD_E_INVAL;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		snprintf(g_err, sizeof(g_err), "no HIP device available");
+		return TFREC_AMD_E_HIP;
+	}
+	if (cfg->device < 0 || cfg->device >= ndev)
+		return TFREC_AMD_E_INVAL;
+	HIPCHK(hipSetDevice(cfg->device));
+
+	tfrec_amd_ctx *c = new (std::nothrow) tfrec_amd_ctx();
+	if (!c)
+		return TFREC_AMD_E_NOMEM;
+	c->cfg = *cfg;
+	memset(&c->launch, 0, sizeof(c->launch));
+
+	// second-stage taps: dsp_stuff.cpp:61-88 (narrow) / :91-117 (wide, -W), pre-shifted for v_mul_hi_i32_i24
+	static const int16_t narrow[20] = { -1087, -1082, -1065, -451, 912, 2997, 5556, 8157, 10285, 11484,
+					    11484, 10285, 8157, 5556, 2997, 912, -451, -1065, -1082, -1087 };
+	static const int16_t wide[20] = { 546, 451, -317, -1844, -3198, -2817, 494, 6469, 13074, 17421,
+					  17421, 13074, 6469, 494, -2817, -3198, -1844, -317, 451, 546 };
+	for (int n = 0; n < 20; n++)
+		c->taps.s2[n] = (int32_t)(cfg->filter_type ? wide[n] : narrow[n]) << 8;
+
+	// registration order, types and samples-per-bit of main.cpp:173-218
+	static const struct {
+		int sensor_type, kind, min_bytes;
+		double baud;
+	} reg[kNSlots] = { { 0, 0, 10, 0 }, { 1, 1, 7, 17240 }, { 2, 1, 7, 9600 }, { 3, 1, 7, 8842 }, { 5, 2, 11, 6000 } };
+	const size_t m_max = (size_t)cfg->max_blocks * kBlockDec;
+	const size_t n = (size_t)cfg->n_streams;
+	int rc = TFREC_AMD_OK;
+#define ALLOC(ptr, bytes)                                                     \
+	do {                                                                  \
+		if (rc == TFREC_AMD_OK && hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { \
+			snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) failed", (size_t)(bytes)); \
+			rc = TFREC_AMD_E_NOMEM;                               \
+		}                                                             \
+	} while (0)
+	for (int s = 0; s < kNSlots && rc == TFREC_AMD_OK; s++) {
+		if (!(cfg->types_mask & (1 << reg[s].sensor_type)))
+			continue;
+		const int a = c->launch.n_active++;
+		c->launch.slot[a] = s;
+		ChainParams &p = c->launch.params[a];
+		memset(&p, 0, sizeof(p));
+		p.kind = reg[s].kind;
+		p.sensor_type = reg[s].sensor_type;
+		p.min_bytes = reg[s].min_bytes;
+		if (p.kind == 0) {
+			p.window = 400;  // 40*BITPERIOD, tfa1.cpp:34, 148
+			p.spb = 10;
+		} else {
+			p.spb = (1536000 / 4.0) / reg[s].baud;
+			if (p.kind == 1) {
+				p.window = d2i_host(16 * p.spb);  // tfa2.cpp:355
+				p.iir = biquad_coef(0.5 / p.spb);  // tfa2.cpp:321
+			} else {
+				p.window = d2i_host(8 * p.spb);         // whb.cpp:641
+				p.iir = biquad_coef(2.0 / p.spb);       // whb.cpp:610
+				p.iir_avg = biquad_coef(0.0025 / p.spb); // whb.cpp:611
+			}
+		}
+		ALLOC(c->launch.states[a], n * sizeof(ChainState));
+		if (rc != TFREC_AMD_OK)
+			break;
+		// constructor state: tfa1.cpp:136-141, tfa2.cpp:316-334, whb.cpp:605-623, decoders :36-45/:54-62/:77-107
+		std::vector<ChainState> init(n);
+		memset(init.data(), 0, n * sizeof(ChainState));
+		for (auto &st : init) {
+			st.sr_cnt = -1;
+			st.dmin = 32767;
+			st.dmax = -32767;
+		}
+		if (hipMemcpy(c->launch.states[a], init.data(), n * sizeof(ChainState), hipMemcpyHostToDevice) != hipSuccess)
+			rc = TFREC_AMD_E_HIP;
+	}
+	c->dec_stride = m_max;
+	c->mask_stride = m_max / 64;
+	ALLOC(c->d_dec, n * c->dec_stride * sizeof(uint32_t));
+	ALLOC(c->d_mask, n * c->mask_stride * sizeof(unsigned long long));
+	ALLOC(c->d_tail[0], n * kTailBytes);
+	ALLOC(c->d_tail[1], n * kTailBytes);
+	ALLOC(c->d_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event));
+	ALLOC(c->d_eb, sizeof(EventBuf));
+#undef ALLOC
+	if (rc == TFREC_AMD_OK) {
+		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
+		EventBuf eb = { 0u, (uint32_t)cfg->max_events, 0ull };
+		if (hipMemset(c->d_tail[0], 0x80, n * kTailBytes) != hipSuccess ||
+		    hipMemset(c->d_tail[1], 0x80, n * kTailBytes) != hipSuccess ||
+		    hipMemcpy(c->d_eb, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess)
+			rc = TFREC_AMD_E_HIP;
+	}
+	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING))
+		for (auto &e : c->ev)
+			if (hipEventCreate(&e) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+	if (rc != TFREC_AMD_OK) {
+		tfrec_amd_destroy(c);
+		return rc;
+	}
+	*out = c;
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int n_blocks, void *hip_stream)
+{
+	if (!c || !d_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
+		return TFREC_AMD_E_INVAL;
+	if ((stride % 16) != 0 || ((uintptr_t)d_iq % 16) != 0 ||
+	    (c->cfg.n_streams > 1 && stride < (size_t)n_blocks * TFREC_AMD_BLOCK_BYTES)) {
+		snprintf(g_err, sizeof(g_err), "IQ base and stream stride must be 16-byte aligned and >= one stream");
+		return TFREC_AMD_E_INVAL;
+	}
+	HIPCHK(hipSetDevice(c->cfg.device));
+	hipStream_t st = (hipStream_t)hip_stream;
+	const bool timing = (c->cfg.flags & TFREC_AMD_F_TIMING) != 0;
+	if (timing)
+		HIPCHK(hipEventRecord(c->ev[0], st));
+	HIPCHK(launch_frontend(st, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
+			       c->d_tail[c->tail_sel ^ 1], c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.thresh,
+			       c->taps));
+	if (timing)
+		HIPCHK(hipEventRecord(c->ev[1], st));
+	HIPCHK(launch_chains(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
+			     c->sample_base, c->launch, c->d_events, c->d_eb, c->cfg.flags));
+	if (timing) {
+		HIPCHK(hipEventRecord(c->ev[2], st));
+		c->timed = true;
+	}
+	c->tail_sel ^= 1;
+	c->sample_base += (long long)n_blocks * kBlockDec;
+	c->last_blocks = n_blocks;
+	c->last_stream = st;
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks)
+{
+	if (!c || !h_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
+		return TFREC_AMD_E_INVAL;
+	const size_t row = (size_t)n_blocks * TFREC_AMD_BLOCK_BYTES;
+	if (c->cfg.n_streams > 1 && stride < row)
+		return TFREC_AMD_E_INVAL;
+	HIPCHK(hipSetDevice(c->cfg.device));
+	const size_t need = row * (size_t)c->cfg.n_streams;
+	if (c->stage_bytes < need) {
+		HIPCHK(hipStreamSynchronize(c->last_stream));
+		(void)hipFree(c->d_stage);
+		c->d_stage = nullptr;
+		c->stage_bytes = 0;
+		if (hipMalloc((void **)&c->d_stage, need) != hipSuccess)
+			return TFREC_AMD_E_NOMEM;
+		c->stage_bytes = need;
+	}
+	// the staging buffer may still be read by the previous submit
+	HIPCHK(hipStreamSynchronize(c->last_stream));
+	HIPCHK(hipMemcpy2D(c->d_stage, row, h_iq, stride, row, (size_t)c->cfg.n_streams, hipMemcpyHostToDevice));
+	return tfrec_amd_submit_device(c, c->d_stage, row, n_blocks, nullptr);
+}
+
+int tfrec_amd_sync(tfrec_amd_ctx *c)
+{
+	if (!c)
+		return TFREC_AMD_E_INVAL;
+	HIPCHK(hipSetDevice(c->cfg.device));
+	HIPCHK(hipStreamSynchronize(c->last_stream));
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
+{
+	if (!c || !n)
+		return TFREC_AMD_E_INVAL;
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	EventBuf eb;
+	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
+	*n = (int)std::min(eb.count, eb.capacity);
+	return eb.count > eb.capacity ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
+}
+
+int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int *n_out)
+{
+	if (!c || !n_out || cap < 0 || (cap > 0 && !out))
+		return TFREC_AMD_E_INVAL;
+	*n_out = 0;
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	EventBuf eb;
+	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
+	const uint32_t have = std::min(eb.count, eb.capacity);
+	bool overflow = eb.count > eb.capacity;
+	std::vector<tfrec_amd_event> tmp(have);
+	if (have)
+		HIPCHK(hipMemcpy(tmp.data(), c->d_events, (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost));
+	std::sort(tmp.begin(), tmp.end(), [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
+		if (a.stream != b.stream)
+			return a.stream < b.stream;
+		if (a.slot != b.slot)
+			return a.slot < b.slot;
+		return a.seq < b.seq;
+	});
+	uint32_t ncopy = have;
+	if (ncopy > (uint32_t)cap) {
+		ncopy = (uint32_t)cap;
+		overflow = true;
+	}
+	if (ncopy)
+		memcpy(out, tmp.data(), (size_t)ncopy * sizeof(tfrec_amd_event));
+	*n_out = (int)ncopy;
+	c->uncertain_total += eb.uncertain;
+	EventBuf fresh = { 0u, (uint32_t)c->cfg.max_events, 0ull };
+	HIPCHK(hipMemcpy(c->d_eb, &fresh, sizeof(fresh), hipMemcpyHostToDevice));
+	return overflow ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
+}
+
+int tfrec_amd_read_decimated(tfrec_amd_ctx *c, int stream, int16_t *out, size_t n_pairs)
+{
+	if (!c || !out || stream < 0 || stream >= c->cfg.n_streams || n_pairs > (size_t)c->last_blocks * kBlockDec)
+		return TFREC_AMD_E_INVAL;
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipMemcpy(out, c->d_dec + (size_t)stream * c->dec_stride, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
+{
+	if (!c || !n)
+		return TFREC_AMD_E_INVAL;
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	EventBuf eb;
+	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
+	*n = c->uncertain_total + eb.uncertain;
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
+{
+	if (!c || !out)
+		return TFREC_AMD_E_INVAL;
+	if (!c->timed)
+		return TFREC_AMD_E_STATE;
+	HIPCHK(hipEventSynchronize(c->ev[2]));
+	HIPCHK(hipEventElapsedTime(&out->frontend_ms, c->ev[0], c->ev[1]));
+	HIPCHK(hipEventElapsedTime(&out->chains_ms, c->ev[1], c->ev[2]));
+	HIPCHK(hipEventElapsedTime(&out->total_ms, c->ev[0], c->ev[2]));
+	return TFREC_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// tfrec_amd/csrc/frontend.hip -- front-end kernel: raw u8 IQ -> decimated int16 IQ + trigger mask.
+//
+// Replaces, for a whole batch of streams, the per-block host work of the reference:
+//   engine.cpp:77-78      s16 = (u8 - 128) << 6
+//   dsp_stuff.cpp:204-230 decimate::process2x1  (8 taps, 2:1, per-tap arithmetic >>16, int16 store)
+//   dsp_stuff.cpp:172-202 decimate::process2x   (20 taps, 2:1, same arithmetic; narrow or -W wide taps)
+//   dsp_stuff.cpp:243-264 downconvert::process_iq (I and Q rails, passes = 2)
+//   fm_demod.cpp:45       pwr = abs(I) + abs(Q), compared with the trigger threshold (tfa1.cpp:147 etc.)
+//
+// Exact integer semantics: with x = (u8-128)<<6,
+//   y1[k] = int16( sum_{n<8}  (x[2k-6+n]  * h1[n]) >> 16 )
+//   y2[m] = int16( sum_{n<20} (y1[2m-18+n] * h2[n]) >> 16 )
+// The per-tap floor shift forbids folding the symmetric taps or summing before shifting.  Stage 1 uses
+// ((u8-128)*h) >> 10 (identical value, the <<6 cancels); stage 2 uses v_mul_hi_i32_i24 on operands
+// pre-shifted by 8 bits: ((y<<8)*(h<<8)) >> 32 == (y*h) >> 16, one full-rate VALU op per tap + one add.
+//
+// MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  The tile's
+// raw bytes (8 KiB + 96 B halo, the halo of the first tile comes from the previous submit's tail) are
+// staged into LDS with coalesced 16-byte loads, stage-1 outputs live only in LDS (pre-shifted int32, read
+// back with ds_read_b128), stage-2 results leave as one 16-byte store per thread, and the trigger bits of
+// 64 consecutive samples are packed into one 64-bit word per wave-quarter with wave ballots.  No MFMA: the
+// path is a streaming stencil, bound by HBM bytes and integer VALU.
+#include "tfrec_dev.h"
+
+namespace tfrec {
+
+// first-stage taps (dsp_stuff.cpp:119-130)
+__device__ __constant__ const int kS1[8] = { 2443, 6339, 11036, 14254, 14254, 11036, 6339, 2443 };
+
+__device__ __forceinline__ int mulhi24(int tap_s8, int y_s8)
+{
+	// bits [47:32] of the 24x24-bit signed product: full-rate VALU (v_mul_hi_i32 would be quarter rate and
+	// the compiler cannot prove the 24-bit ranges of run-time taps / LDS values by itself)
+	int r;
+	asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(r) : "s"(tap_s8), "v"(y_s8));
+	return r;
+}
+
+__device__ __forceinline__ unsigned long long spread4(unsigned long long x)
+{
+	// bit i of the 16-bit input moves to bit 4*i
+	x = (x | (x << 24)) & 0x000000FF000000FFull;
+	x = (x | (x << 12)) & 0x000F000F000F000Full;
+	x = (x | (x << 6)) & 0x0303030303030303ull;
+	x = (x | (x << 3)) & 0x1111111111111111ull;
+	return x;
+}
+
+__global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
+	const uint8_t *__restrict__ iq, size_t stride, int m_total, const uint8_t *__restrict__ tail_in,
+	uint8_t *__restrict__ tail_out, uint32_t *__restrict__ dec, size_t dec_stride,
+	unsigned long long *__restrict__ mask, size_t mask_stride, int thresh, FrontTaps taps)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t raw[kRawChunks * 16];
+	__shared__ __attribute__((aligned(16))) int32_t y1i[kY1Count];
+	__shared__ __attribute__((aligned(16))) int32_t y1q[kY1Count];
+
+	const int s = blockIdx.y;
+	const int tile = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int m0 = tile * kTileDec;
+	const long nbytes = 8L * m_total;
+	const uint8_t *src = iq + (size_t)s * stride;
+
+	// ---- stage raw bytes [8*m0 - 96, 8*m0 + 8*T + 16) into LDS, 16 B per lane, coalesced
+	const long base = 8L * m0 - kTailBytes;
+	for (int c = tid; c < kRawChunks; c += kFrontThreads) {
+		const long bo = base + 16L * c;
+		uint4 v;
+		if (bo >= 0 && bo + 16 <= nbytes)
+			v = *reinterpret_cast<const uint4 *>(src + bo);
+		else if (bo < 0)
+			v = *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTailBytes + (kTailBytes + bo));
+		else
+			v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+		*reinterpret_cast<uint4 *>(raw + 16 * c) = v;
+	}
+	// history for the next submit: last 96 raw bytes of this one
+	if (tile == (int)gridDim.x - 1 && tid < kTailBytes / 16)
+		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTailBytes + 16 * tid) =
+			*reinterpret_cast<const uint4 *>(src + nbytes - kTailBytes + 16 * tid);
+	__syncthreads();
+
+	// ---- stage 1: local output j <-> y1[2*m0 - 18 + j]; a lane makes 4 consecutive outputs of both rails.
+	// It needs x[2k-6 .. 2k+7] for k = 2*m0-18+4*grp, i.e. 28 raw bytes at LDS offset 12 + 16*grp.
+	constexpr int kGroups = (2 * kTileDec + 18 + 3) / 4;
+	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
+		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + 12 + 16 * grp);
+		int di[14], dq[14];
+#pragma unroll
+		for (int i = 0; i < 7; i++) {
+			const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
+			di[2 * i] = (int)(int8_t)(w & 0xff);
+			dq[2 * i] = (int)(int8_t)((w >> 8) & 0xff);
+			di[2 * i + 1] = (int)(int8_t)((w >> 16) & 0xff);
+			dq[2 * i + 1] = (int)w >> 24;
+		}
+		int oi[4], oq[4];
+#pragma unroll
+		for (int o = 0; o < 4; o++) {
+			int si = 0, sq = 0;
+#pragma unroll
+			for (int n = 0; n < 8; n++) {
+				si += (di[2 * o + n] * kS1[n]) >> 10;
+				sq += (dq[2 * o + n] * kS1[n]) >> 10;
+			}
+			oi[o] = (int)(int16_t)si << 8;
+			oq[o] = (int)(int16_t)sq << 8;
+		}
+		*reinterpret_cast<int4 *>(&y1i[4 * grp]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+		*reinterpret_cast<int4 *>(&y1q[4 * grp]) = make_int4(oq[0], oq[1], oq[2], oq[3]);
+	}
+	__syncthreads();
+
+	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs y1 local [8*tid + 2*o, +20)
+	int yi[28], yq[28];
+#pragma unroll
+	for (int i = 0; i < 7; i++) {
+		const int4 a = *reinterpret_cast<const int4 *>(&y1i[8 * tid + 4 * i]);
+		const int4 b = *reinterpret_cast<const int4 *>(&y1q[8 * tid + 4 * i]);
+		yi[4 * i] = a.x; yi[4 * i + 1] = a.y; yi[4 * i + 2] = a.z; yi[4 * i + 3] = a.w;
+		yq[4 * i] = b.x; yq[4 * i + 1] = b.y; yq[4 * i + 2] = b.z; yq[4 * i + 3] = b.w;
+	}
+	uint32_t outw[4];
+	bool trig[4];
+#pragma unroll
+	for (int o = 0; o < 4; o++) {
+		int si = 0, sq = 0;
+#pragma unroll
+		for (int n = 0; n < 20; n++) {
+			si += mulhi24(taps.s2[n], yi[2 * o + n]);
+			sq += mulhi24(taps.s2[n], yq[2 * o + n]);
+		}
+		const int I = (int)(int16_t)si, Q = (int)(int16_t)sq;
+		outw[o] = ((uint32_t)I & 0xffffu) | ((uint32_t)Q << 16);
+		trig[o] = (abs(I) + abs(Q)) > thresh;
+	}
+	*reinterpret_cast<uint4 *>(dec + (size_t)s * dec_stride + m0 + 4 * tid) =
+		make_uint4(outw[0], outw[1], outw[2], outw[3]);
+
+	// ---- trigger mask: bit b of word w <-> decimated sample 64*w + b
+	const unsigned long long b0 = __ballot(trig[0]), b1 = __ballot(trig[1]), b2 = __ballot(trig[2]),
+				 b3 = __ballot(trig[3]);
+	const int lane = tid & 63, wave = tid >> 6;
+	if (lane < 4) {
+		const int sh = 16 * lane;
+		const unsigned long long w = spread4((b0 >> sh) & 0xffff) | (spread4((b1 >> sh) & 0xffff) << 1) |
+					     (spread4((b2 >> sh) & 0xffff) << 2) | (spread4((b3 >> sh) & 0xffff) << 3);
+		mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + lane] = w;
+	}
+}
+
+hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
+			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
+			   unsigned long long *mask, size_t mask_stride, int thresh, const FrontTaps &taps)
+{
+	const int m_total = n_blocks * kBlockDec;
+	dim3 grid(m_total / kTileDec, n_streams);
+	hipLaunchKernelGGL(frontend_kernel, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out, dec,
+			   dec_stride, mask, mask_stride, thresh, taps);
+	return hipGetLastError();
+}
+
+}  // namespace tfrec

@@ -1,0 +1,89 @@
+// tfrec_amd/csrc/tfrec_dev.h -- device-side data layout shared by the kernels and the C-ABI glue.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/tfrec_amd.h"
+
+namespace tfrec {
+
+constexpr int kBlockDec = TFREC_AMD_BLOCK_DEC;  // 8192 decimated pairs per reference block
+constexpr int kIndexSpan = 2 * kBlockDec;       // 'len' of fsk_demod::process / demodulator::start (fm_demod.cpp:38-40)
+constexpr int kTailBytes = 96;                  // raw bytes of FIR history carried between submits (48 complex samples
+                                                // >= the 46-sample halo of the 8+20 tap cascade, dsp_stuff.cpp:172-230)
+constexpr int kNSlots = TFREC_AMD_NSLOTS;
+
+// ---- front-end tile geometry
+constexpr int kTileDec = 1024;                       // decimated outputs per workgroup tile
+constexpr int kFrontThreads = 256;
+constexpr int kRawChunks = (kTailBytes + 8 * kTileDec + 16 + 15) / 16;  // 16-byte chunks staged per tile
+constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per channel (need 2*T+18)
+
+// Second-stage taps, pre-shifted by 8 for v_mul_hi_i32_i24 (see frontend.hip).
+struct FrontTaps {
+	int32_t s2[20];
+};
+
+// ---- biquad (dsp_stuff.cpp:28-56); state as the reference's members, coefficients in FrontParams
+struct Biquad {
+	double dn1, dn2, yn, yn1;
+};
+
+struct BiquadCoef {
+	double b0, b1, b2, a1, a2;
+};
+
+// ---- persistent per-(stream, slot) demodulator + decoder state.  Field names follow the reference members
+// (tfa1.h:25-33, tfa2.h:30-43, whb.h:44-60, decoder.h:49-57).
+struct ChainState {
+	// demodulator
+	int32_t last_bit_idx;  // decoder.h:72 (block-relative int16 index units, rebased by demodulator::start)
+	int32_t timeout_cnt;
+	int32_t mark_lvl;      // tfa1
+	int32_t rssi_i;        // tfa1 / tfa2 integer rssi
+	int32_t bitcnt, dmin, dmax, offset, last_bit;  // tfa2
+	int32_t last_dev, avg_of;                      // whb
+	int32_t prev_i, prev_q;                        // last_i/last_q: previous decimated sample
+	uint64_t step, last_peak;                      // whb
+	double rssi_d;                                 // whb
+	Biquad iir, iir_avg;
+	// decoder
+	uint32_t sr;
+	int32_t sr_cnt, byte_cnt, invert, synced;
+	int32_t w_last_bit, psk, last_psk, nrzs;  // whb descrambler chain
+	uint32_t lfsr;
+	uint32_t seq;  // flush ordinal
+	uint32_t pad_;
+	uint8_t rdata[256];
+};
+
+struct ChainParams {
+	int32_t kind;        // 0 tfa1, 1 tfa2 family, 2 whb
+	int32_t sensor_type; // sensor_e value (decoder.h:11-19)
+	int32_t window;      // timeout reload: 400 / (int)(16*spb) / (int)(8*spb)
+	int32_t min_bytes;   // smallest byte_cnt a flush can turn into a telegram
+	double spb;
+	BiquadCoef iir, iir_avg;
+};
+
+// everything one chains launch needs, passed by value as kernel argument
+struct ChainLaunch {
+	int32_t n_active;
+	int32_t slot[kNSlots];
+	ChainState *states[kNSlots];
+	ChainParams params[kNSlots];
+};
+
+struct EventBuf {
+	uint32_t count;     // events appended (may exceed capacity -> overflow)
+	uint32_t capacity;
+	unsigned long long uncertain;  // fm_dev results within 1e-9 of a truncation boundary
+};
+
+static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
+static_assert(offsetof(tfrec_amd_event, rdata) == 32, "event rdata offset");
+static_assert(offsetof(ChainState, rdata) % 16 == 0 && sizeof(ChainState) % 16 == 0, "ChainState rdata must be 16-byte aligned");
+
+}  // namespace tfrec
