@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ MSamples/s through full demod+decode on batched synthetic 1.536 MS/s streams.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run, one rank
+per GPU).  A step = one pass of the hot path (front-end FIR kernel + demodulator/decoder chains + event
+drain to the host) over one batch of synthetic input that is already resident in HBM.
+
+Workload (BASELINE.json configs[2], the configuration the "batched streams" metric is quoted on):
+1024 streams x 48 blocks (1.024 s of signal each = 1 572 864 complex samples) x all five protocols,
+fixed threshold -t 500, per GPU.  With N GPUs every rank gets its own 1024 streams (configs[3] at N=8:
+8192 streams, weak scaling, no collective on the data path -- streams are independent).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     dominant kernel vs the HBM roofline (algorithmic bytes = 2 B per complex input sample),
+  "cpu_baseline": the reference CPU path timed on this box's host cores (1 thread) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SAMPLES_PER_BLOCK = 32768
+
+
+def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float):
+    """Time the reference CPU path, 1 thread, on a bounded sample of the same workload.
+
+    kind "reference": the real reference hot path (oracle/_ref/ref_driver, compiled from /root/reference
+    in the build container) -- used when the binary travelled with the tree; else kind "port": the C
+    restatement oracle/tfrec_oracle.c (proven equal to the reference by tests/golden)."""
+    from oracle import oracle as O
+
+    n_streams = iq_sample.shape[0]
+    samples_per_stream = iq_sample.shape[1] // 2
+    # port
+    t0 = time.perf_counter()
+    done = 0
+    for s in range(n_streams):
+        o = O.Oracle(types, thresh, 0, quiet=True)
+        o.process(iq_sample[s])
+        o.close()
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    t_port = time.perf_counter() - t0
+    port = done * samples_per_stream / t_port / 1e6
+    res = dict(value=round(port, 3), unit="MSamples/s", cores=1, kind="port",
+               sample="%d streams x %d blocks of the bench batch, oracle/tfrec_oracle.c, 1 thread" % (
+                   done, samples_per_stream // SAMPLES_PER_BLOCK))
+    if os.path.exists(O.REF_DRIVER):
+        with tempfile.TemporaryDirectory() as tmp:
+            p = os.path.join(tmp, "s.iq")
+            k = max(1, min(n_streams, done))
+            np.ascontiguousarray(iq_sample[:k]).tofile(p)  # streams back to back: one long stream for the reference
+            try:
+                out = subprocess.run([O.REF_DRIVER, "time", "%x" % types, str(thresh), "0", p, "1"],
+                                     capture_output=True, text=True, check=True, timeout=600)
+                r = json.loads(out.stderr.strip().splitlines()[-1])
+                res = dict(value=round(r["msps"], 3), unit="MSamples/s", cores=1, kind="reference",
+                           sample="%d streams x %d blocks of the bench batch concatenated, real reference hot path "
+                                  "(oracle/_ref/ref_driver, g++ -O3 -ffast-math as the reference Makefile), 1 thread"
+                                  % (k, samples_per_stream // SAMPLES_PER_BLOCK),
+                           port_value=round(port, 3))
+            except Exception as e:  # keep the port number
+                res["reference_error"] = str(e)[:200]
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--blocks", type=int, default=48, help="65536-byte blocks per stream per step")
+    ap.add_argument("--types", type=lambda x: int(x, 16), default=0x2F)
+    ap.add_argument("--thresh", type=int, default=500)
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic streams to generate per GPU (0 = auto)")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--parity-streams", type=int, default=4)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from tfrec_amd import api, synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_streams, n_blocks = a.streams, a.blocks
+    row = n_blocks * api.BLOCK_BYTES
+    # ---- synthetic input: distinct seeds per rank; generate `unique` streams and tile them over the batch
+    ncpu = os.cpu_count() or 1
+    unique = a.unique if a.unique > 0 else (n_streams if ncpu >= 32 else min(n_streams, max(16, 8 * ncpu)))
+    t0 = time.perf_counter()
+    host = synth.gen_batch(1000 + rank, rank * n_streams, unique, n_blocks)
+    t_gen = time.perf_counter() - t0
+    d_iq = torch.empty((n_streams, row), dtype=torch.uint8, device=dev)
+    d_u = torch.from_numpy(host).to(dev)
+    for s0 in range(0, n_streams, unique):
+        k = min(unique, n_streams - s0)
+        d_iq[s0:s0 + k].copy_(d_u[:k])
+    del d_u
+    torch.cuda.synchronize(dev)
+
+    r = api.Receiver(n_streams, a.types, a.thresh, 0, device=local_rank, max_blocks=n_blocks, timing=True,
+                     max_events=max(4096, n_streams * 256))
+
+    # ---- parity gate on this rank's first streams (fresh context state): GPU events == oracle events
+    parity_ok = None
+    first = None
+    if a.parity_streams > 0:
+        from oracle import oracle as O
+        r.submit(d_iq)
+        first = r.drain()
+        minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
+        parity_ok = True
+        for s in range(min(a.parity_streams, unique)):
+            o = O.Oracle(a.types, a.thresh, 0)
+            o.process(host[s])
+            want = sorted(e for e in o.events() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
+                          and not (e[0] == 4 and e[2] > 60))
+            got = sorted(api.event_tuples(first, s))
+            parity_ok = parity_ok and (got == want)
+        if not parity_ok:
+            print("PARITY FAILURE on rank %d" % rank, file=sys.stderr)
+            sys.exit(3)
+
+    def step():
+        r.submit(d_iq)
+        return r.drain()
+
+    for _ in range(a.warmup):
+        step()
+    fe_ms, ch_ms, n_events = [], [], 0
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ev = step()
+        n_events += len(ev)
+        t = r.timings()  # HIP events recorded on the stream the kernels were launched on
+        fe_ms.append(t["frontend_ms"])
+        ch_ms.append(t["chains_ms"])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    samples_per_step_gpu = n_streams * n_blocks * SAMPLES_PER_BLOCK
+    total_samples = samples_per_step_gpu * a.steps * world
+    value = total_samples / elapsed / 1e6
+
+    if rank == 0:
+        fe = float(np.mean(fe_ms)) if fe_ms else 0.0
+        ch = float(np.mean(ch_ms)) if ch_ms else 0.0
+        dom_name, dom_ms = ("chains_kernel", ch) if ch >= fe else ("frontend_kernel", fe)
+        alg_bytes = 2.0 * samples_per_step_gpu  # 2 B per complex input sample, one launch = one batch
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "IQ MSamples/s through demod+decode (batched streams)",
+            "value": round(value, 3),
+            "unit": "MSamples/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32+f64",
+            "data": "synthetic (tfrec_amd.synth, SURVEY App. C recipe; %d distinct streams per GPU tiled over %d)" % (
+                unique, n_streams),
+            "config": {
+                "workload": "configs[2]: %d batched 1.536 MS/s streams x %d blocks x protocols mask 0x%x, -t %d, per GPU"
+                            % (n_streams, n_blocks, a.types, a.thresh),
+                "streams_per_gpu": n_streams, "blocks_per_stream": n_blocks, "types_mask": a.types,
+                "thresh": a.thresh, "parallelism": "streams sharded by index, no collective",
+                "events_per_step": n_events // max(1, a.steps), "parity_gate_streams": a.parity_streams,
+                "parity_ok": parity_ok, "gen_seconds": round(t_gen, 2),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernels_ms": {"frontend_kernel": round(fe, 4), "chains_kernel": round(ch, 4)},
+                "frontend_achieved_GBs": round(alg_bytes / (fe * 1e-3) / 1e9, 2) if fe > 0 else None,
+            },
+        }
+        if a.cpu_budget > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(host[: min(unique, 64)], a.types, a.thresh, a.cpu_budget)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""CPU tests of the C-ABI shared library and the host-side logic: the library loads, exports every symbol
+include/tfrec_amd.h declares, validates arguments, and fails LOUDLY without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tfrec_amd import api, shard, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tfrec_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(tfrec_amd_[a-z_]+)\s*\(", hdr)))
+    assert set(declared) == set(api.EXPORTS)
+    L = api.load_library()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.tfrec_amd_version().startswith(b"tfrec_amd")
+    assert C.sizeof(api.Config) == 32 and api.EVENT_DTYPE.itemsize == 96
+
+
+def test_argument_validation_precedes_device_use():
+    L = api.load_library()
+    h = C.c_void_p()
+    bad = api.Config(0, 0x2F, 500, 0, 0, 8, 1024, 0)  # n_streams = 0
+    assert L.tfrec_amd_create(C.byref(bad), C.byref(h)) == api.E_INVAL
+    auto = api.Config(4, 0x2F, 0, 0, 0, 8, 1024, 0)  # auto threshold not offered
+    assert L.tfrec_amd_create(C.byref(auto), C.byref(h)) == api.E_INVAL
+    assert L.tfrec_amd_create(None, C.byref(h)) == api.E_INVAL
+    assert L.tfrec_amd_destroy(None) == api.E_OK
+    assert L.tfrec_amd_strerror(api.E_OVERFLOW) == b"event buffer overflow"
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_gpu_fails_loudly_no_cpu_fallback():
+    with pytest.raises(api.TfrecAmdError) as e:
+        api.Receiver(4)
+    assert e.value.code == api.E_HIP
+
+
+def test_host_rssi_db_matches_reference_expressions():
+    from oracle import oracle as O
+    iq = synth.gen_stream(7, 0, 48)
+    o = O.Oracle(0x2F, 500)
+    o.process(iq)
+    evs = o.events_raw()
+    assert len(evs) > 50
+    for (slot, _end, _bc, rssi_db, _off, _rd), raw in evs:
+        assert api.rssi_db(slot, raw) == rssi_db
+    # (int)(10*log10(0)) and negative/NaN cases behave like x86 cvttsd2si
+    assert api.rssi_db(0, 0) == -2147483648
+    assert api.rssi_db(1, -5) == -2147483648
+    assert api.rssi_db(4, 0) == 0
+
+
+def test_shard_ranges_cover_every_stream_once():
+    for n in (1, 7, 8, 1024, 8192, 8191):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                a, b = shard.shard_range(r, w, n)
+                seen.extend(range(a, b))
+            assert seen == list(range(n))
+
+
+def test_generator_is_deterministic_and_decodable():
+    a = synth.gen_stream(99, 5, 8)
+    b, truth = synth.gen_stream(99, 5, 8, with_truth=True)
+    assert np.array_equal(a, b) and len(truth) >= 2
+    c = synth.gen_batch(99, 4, 3, 8)
+    assert np.array_equal(c[1], a)
+    assert all(t["frame"][:2] in (b"\x2d\xd4", b"\x4b\x2d") for t in truth)
