@@ -55,6 +55,8 @@ enum {
 				      only flushes whose byte_cnt reaches the decoder's minimum length
 				      (tfa1.cpp:49, tfa2.cpp:76/222, whb.cpp:484) */
 #define TFREC_AMD_F_TIMING 2u      /* record HIP events around every kernel (tfrec_amd_get_timings) */
+#define TFREC_AMD_F_SERIAL_CHAINS 4u /* run the demodulators as one serial lane per (stream, slot) -- the simple
+				      GPU formulation kept as a cross-check of the window-parallel pipeline */
 
 typedef struct {
 	int32_t n_streams;   /* independent IQ streams in the batch (>=1) */

@@ -54,10 +54,14 @@ def test_frontend_bit_exact(wide):
             assert np.array_equal(got, want), "stream %d" % s
 
 
-def test_all_flush_events_match_oracle():
+SERIAL = pytest.mark.parametrize("serial", [False, True], ids=["pipeline", "serial"])
+
+
+@SERIAL
+def test_all_flush_events_match_oracle(serial):
     n_streams, n_blocks = 24, 48
     iq = synth.gen_batch(7, 0, n_streams, n_blocks)
-    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True) as r:
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True, serial_chains=serial) as r:
         r.submit(iq)
         ev = r.drain()
         total = 0
@@ -82,10 +86,11 @@ def test_default_mode_reports_candidates_with_verdict():
             assert n_ok == len(lines)
 
 
-def test_state_carries_across_submits():
+@SERIAL
+def test_state_carries_across_submits(serial):
     n_streams = 5
     iq = synth.gen_batch(11, 7, n_streams, 24)
-    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=16, all_flushes=True) as r:
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=16, all_flushes=True, serial_chains=serial) as r:
         evs = []
         pos = 0
         for nb in (1, 7, 3, 13):
@@ -98,11 +103,12 @@ def test_state_carries_across_submits():
             check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
 
 
+@SERIAL
 @pytest.mark.parametrize("types,thresh", [(0x01, 500), (0x07, 500), (0x20, 300), (0x0E, 1500)])
-def test_type_masks_and_thresholds(types, thresh):
+def test_type_masks_and_thresholds(types, thresh, serial):
     n_streams, n_blocks = 6, 24
     iq = synth.gen_batch(13, 3, n_streams, n_blocks, noise_q8=512)
-    with api.Receiver(n_streams, types, thresh, 0, max_blocks=n_blocks, all_flushes=True) as r:
+    with api.Receiver(n_streams, types, thresh, 0, max_blocks=n_blocks, all_flushes=True, serial_chains=serial) as r:
         r.submit(iq)
         ev = r.drain()
         for s in range(n_streams):

@@ -10,7 +10,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_SO = os.path.join(_PKG, "libtfrec_amd.so")
 HOST_SO = os.path.join(_PKG, "libtfrec_host.so")
 
-HIP_SOURCES = ["frontend.hip", "chains.hip", "capi.hip"]
+HIP_SOURCES = ["frontend.hip", "chains.hip", "chains2.hip", "capi.hip"]
 # -ffp-contract=off: the demodulator biquads must round after every multiply and add (bit-exact parity);
 # no fast-math anywhere.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -34,7 +34,7 @@ def hipcc() -> str:
 def build_device_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into tfrec_amd/libtfrec_amd.so."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "tfrec_dev.h"), os.path.join(ROOT, "include", "tfrec_amd.h"), __file__]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("tfrec_dev.h", "dsp_dev.h", "decoder_dev.h")] + [ os.path.join(ROOT, "include", "tfrec_amd.h"), __file__]
     if force or _stale(LIB_SO, deps):
         objs = []
         for s in srcs:

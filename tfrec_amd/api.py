@@ -20,6 +20,7 @@ SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
 
 F_ALL_FLUSHES = 1
 F_TIMING = 2
+F_SERIAL_CHAINS = 4
 
 E_OK, E_INVAL, E_NOMEM, E_HIP, E_OVERFLOW, E_STATE = 0, -1, -2, -3, -4, -5
 
@@ -137,11 +138,12 @@ class Receiver:
 
     def __init__(self, n_streams: int, types_mask: int = 0x2F, thresh: int = 500, filter_type: int = 0,
                  device: int = 0, max_blocks: int = 48, max_events: int | None = None, all_flushes: bool = False,
-                 timing: bool = False):
+                 timing: bool = False, serial_chains: bool = False):
         self.L = load_library()
         if max_events is None:
             max_events = max(4096, n_streams * max_blocks * 4 * (8 if all_flushes else 2))
-        flags = (F_ALL_FLUSHES if all_flushes else 0) | (F_TIMING if timing else 0)
+        flags = ((F_ALL_FLUSHES if all_flushes else 0) | (F_TIMING if timing else 0)
+                 | (F_SERIAL_CHAINS if serial_chains else 0))
         self.cfg = Config(n_streams, types_mask, thresh, filter_type, device, max_blocks, max_events, flags)
         self.h = C.c_void_p()
         _check(self.L, self.L.tfrec_amd_create(C.byref(self.cfg), C.byref(self.h)))

@@ -12,7 +12,12 @@
 namespace tfrec {
 hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
-			   unsigned long long *mask, size_t mask_stride, int thresh, const FrontTaps &taps);
+			   unsigned long long *mask, size_t mask_stride, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
+			   int thresh, const FrontTaps &taps);
+hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
+			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
+			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			 size_t mask_stride, int n_streams, int n_blocks, long long sample_base, const ChainLaunch &L,
 			 tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
@@ -42,6 +47,12 @@ struct tfrec_amd_ctx {
 	size_t dec_stride = 0;  // uint32 units
 	unsigned long long *d_mask = nullptr;
 	size_t mask_stride = 0;
+	int16_t *d_fmdev = nullptr;  // [n_streams][m_max] fm_dev of every decimated sample
+	int16_t *d_ld16 = nullptr;   // [chains][m_max] tfa2-family biquad outputs
+	int32_t *d_dev32 = nullptr;  // [n_streams][m_max] WHB stage-1 outputs
+	WinTables win;
+	void *win_block = nullptr;
+	int32_t *h_overflow_dummy = nullptr;
 	uint8_t *d_tail[2] = { nullptr, nullptr };
 	int tail_sel = 0;
 	tfrec_amd_event *d_events = nullptr;
@@ -138,6 +149,10 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 			(void)hipFree(c->launch.states[a]);
 	(void)hipFree(c->d_dec);
 	(void)hipFree(c->d_mask);
+	(void)hipFree(c->d_fmdev);
+	(void)hipFree(c->d_ld16);
+	(void)hipFree(c->d_dev32);
+	(void)hipFree(c->win_block);
 	(void)hipFree(c->d_tail[0]);
 	(void)hipFree(c->d_tail[1]);
 	(void)hipFree(c->d_events);
@@ -180,6 +195,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		return TFREC_AMD_E_NOMEM;
 	c->cfg = *cfg;
 	memset(&c->launch, 0, sizeof(c->launch));
+	memset(&c->win, 0, sizeof(c->win));
 
 	// second-stage taps: dsp_stuff.cpp:61-88 (narrow) / :91-117 (wide, -W), pre-shifted for v_mul_hi_i32_i24
 	static const int16_t narrow[20] = { -1087, -1082, -1065, -451, 912, 2997, 5556, 8157, 10285, 11484,
@@ -246,6 +262,47 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	c->mask_stride = m_max / 64;
 	ALLOC(c->d_dec, n * c->dec_stride * sizeof(uint32_t));
 	ALLOC(c->d_mask, n * c->mask_stride * sizeof(unsigned long long));
+	ALLOC(c->d_fmdev, n * m_max * sizeof(int16_t));
+	if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
+		// window-parallel pipeline buffers (chains2.hip)
+		const size_t chains = (size_t)c->launch.n_active * n;
+		bool whb = false;
+		for (int a = 0; a < c->launch.n_active; a++)
+			whb = whb || c->launch.params[a].kind == 2;
+		ALLOC(c->d_ld16, chains * m_max * sizeof(int16_t));
+		if (whb)
+			ALLOC(c->d_dev32, n * m_max * sizeof(int32_t));
+		WinTables &T = c->win;
+		T.cap = (int32_t)(m_max / 356 + 2);  // windows of one chain are > W-1 >= 355 samples apart
+		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
+		const size_t wins = chains * (size_t)T.cap;
+		size_t off = 0;
+		auto carve = [&](size_t bytes) {
+			const size_t o = off;
+			off += (bytes + 255) & ~(size_t)255;
+			return o;
+		};
+		const size_t o_count = carve(chains * 4), o_cont = carve(chains * 4), o_tnext = carve(chains * 4);
+		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
+		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve(4 * wins * sizeof(uint2));
+		const size_t o_queue = carve(4 * sizeof(WorkQueue)), o_ovf = carve(4);
+		ALLOC(c->win_block, off);
+		if (rc == TFREC_AMD_OK) {
+			uint8_t *b = (uint8_t *)c->win_block;
+			T.count = (int32_t *)(b + o_count);
+			T.cont = (int32_t *)(b + o_cont);
+			T.timeout_next = (int32_t *)(b + o_tnext);
+			T.open = (int32_t *)(b + o_open);
+			T.close = (int32_t *)(b + o_close);
+			T.result = (WinResult *)(b + o_res);
+			T.bits = (uint32_t *)(b + o_bits);
+			T.items = (uint2 *)(b + o_items);
+			T.queue = (WorkQueue *)(b + o_queue);
+			T.overflow = (int32_t *)(b + o_ovf);
+			if (hipMemset(T.queue, 0, 4 * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+		}
+	}
 	ALLOC(c->d_tail[0], n * kTailBytes);
 	ALLOC(c->d_tail[1], n * kTailBytes);
 	ALLOC(c->d_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event));
@@ -286,12 +343,17 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[0], st));
 	HIPCHK(launch_frontend(st, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
-			       c->d_tail[c->tail_sel ^ 1], c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.thresh,
-			       c->taps));
+			       c->d_tail[c->tail_sel ^ 1], c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev,
+			       c->dec_stride, c->d_eb, c->cfg.thresh, c->taps));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[1], st));
-	HIPCHK(launch_chains(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
-			     c->sample_base, c->launch, c->d_events, c->d_eb, c->cfg.flags));
+	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)
+		HIPCHK(launch_chains(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
+				     c->sample_base, c->launch, c->d_events, c->d_eb, c->cfg.flags));
+	else
+		HIPCHK(launch_pipeline(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev, c->dec_stride,
+				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16, c->d_dev32,
+				       c->d_events, c->d_eb, c->cfg.flags, 768));
 	if (timing) {
 		HIPCHK(hipEventRecord(c->ev[2], st));
 		c->timed = true;
@@ -361,6 +423,14 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
 	const uint32_t have = std::min(eb.count, eb.capacity);
 	bool overflow = eb.count > eb.capacity;
+	if (c->win.overflow) {
+		int32_t wov = 0;
+		HIPCHK(hipMemcpy(&wov, c->win.overflow, 4, hipMemcpyDeviceToHost));
+		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
+			snprintf(g_err, sizeof(g_err), "window table overflow");
+			return TFREC_AMD_E_STATE;
+		}
+	}
 	std::vector<tfrec_amd_event> tmp(have);
 	if (have)
 		HIPCHK(hipMemcpy(tmp.data(), c->d_events, (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost));

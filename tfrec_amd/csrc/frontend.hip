@@ -15,12 +15,12 @@
 // pre-shifted by 8 bits: ((y<<8)*(h<<8)) >> 32 == (y*h) >> 16, one full-rate VALU op per tap + one add.
 //
 // MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  The tile's
-// raw bytes (8 KiB + 96 B halo, the halo of the first tile comes from the previous submit's tail) are
+// raw bytes (8 KiB + 112 B halo, the halo of the first tile comes from the previous submit's tail) are
 // staged into LDS with coalesced 16-byte loads, stage-1 outputs live only in LDS (pre-shifted int32, read
 // back with ds_read_b128), stage-2 results leave as one 16-byte store per thread, and the trigger bits of
 // 64 consecutive samples are packed into one 64-bit word per wave-quarter with wave ballots.  No MFMA: the
 // path is a streaming stencil, bound by HBM bytes and integer VALU.
-#include "tfrec_dev.h"
+#include "dsp_dev.h"
 
 namespace tfrec {
 
@@ -49,11 +49,13 @@ __device__ __forceinline__ unsigned long long spread4(unsigned long long x)
 __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const uint8_t *__restrict__ iq, size_t stride, int m_total, const uint8_t *__restrict__ tail_in,
 	uint8_t *__restrict__ tail_out, uint32_t *__restrict__ dec, size_t dec_stride,
-	unsigned long long *__restrict__ mask, size_t mask_stride, int thresh, FrontTaps taps)
+	unsigned long long *__restrict__ mask, size_t mask_stride, int16_t *__restrict__ fmdev, size_t fmdev_stride,
+	EventBuf *__restrict__ eb, int thresh, FrontTaps taps)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t raw[kRawChunks * 16];
 	__shared__ __attribute__((aligned(16))) int32_t y1i[kY1Count];
 	__shared__ __attribute__((aligned(16))) int32_t y1q[kY1Count];
+	__shared__ uint32_t lastw[kFrontThreads];
 
 	const int s = blockIdx.y;
 	const int tile = blockIdx.x;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const long nbytes = 8L * m_total;
 	const uint8_t *src = iq + (size_t)s * stride;
 
-	// ---- stage raw bytes [8*m0 - 96, 8*m0 + 8*T + 16) into LDS, 16 B per lane, coalesced
+	// ---- stage raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) into LDS, 16 B per lane, coalesced
 	const long base = 8L * m0 - kTailBytes;
 	for (int c = tid; c < kRawChunks; c += kFrontThreads) {
 		const long bo = base + 16L * c;
@@ -75,15 +77,15 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
 		*reinterpret_cast<uint4 *>(raw + 16 * c) = v;
 	}
-	// history for the next submit: last 96 raw bytes of this one
+	// history for the next submit: last 112 raw bytes of this one
 	if (tile == (int)gridDim.x - 1 && tid < kTailBytes / 16)
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTailBytes + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTailBytes + 16 * tid);
 	__syncthreads();
 
-	// ---- stage 1: local output j <-> y1[2*m0 - 18 + j]; a lane makes 4 consecutive outputs of both rails.
-	// It needs x[2k-6 .. 2k+7] for k = 2*m0-18+4*grp, i.e. 28 raw bytes at LDS offset 12 + 16*grp.
-	constexpr int kGroups = (2 * kTileDec + 18 + 3) / 4;
+	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes 4 consecutive outputs of both rails.
+	// Outputs k..k+3 need x[2k-6 .. 2k+7]: 28 raw bytes at LDS offset 12 + 16*grp (k = 2*m0 - 22 + 4*grp).
+	constexpr int kGroups = (2 * kTileDec + 24 + 3) / 4;
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
 		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + 12 + 16 * grp);
 		int di[14], dq[14];
@@ -112,15 +114,16 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	}
 	__syncthreads();
 
-	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs y1 local [8*tid + 2*o, +20)
+	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs LDS slots [8*tid + 4 + 2*o, +20)
 	int yi[28], yq[28];
 #pragma unroll
 	for (int i = 0; i < 7; i++) {
-		const int4 a = *reinterpret_cast<const int4 *>(&y1i[8 * tid + 4 * i]);
-		const int4 b = *reinterpret_cast<const int4 *>(&y1q[8 * tid + 4 * i]);
+		const int4 a = *reinterpret_cast<const int4 *>(&y1i[8 * tid + 4 + 4 * i]);
+		const int4 b = *reinterpret_cast<const int4 *>(&y1q[8 * tid + 4 + 4 * i]);
 		yi[4 * i] = a.x; yi[4 * i + 1] = a.y; yi[4 * i + 2] = a.z; yi[4 * i + 3] = a.w;
 		yq[4 * i] = b.x; yq[4 * i + 1] = b.y; yq[4 * i + 2] = b.z; yq[4 * i + 3] = b.w;
 	}
+	int oI[4], oQ[4];
 	uint32_t outw[4];
 	bool trig[4];
 #pragma unroll
@@ -131,9 +134,10 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			si += mulhi24(taps.s2[n], yi[2 * o + n]);
 			sq += mulhi24(taps.s2[n], yq[2 * o + n]);
 		}
-		const int I = (int)(int16_t)si, Q = (int)(int16_t)sq;
-		outw[o] = ((uint32_t)I & 0xffffu) | ((uint32_t)Q << 16);
-		trig[o] = (abs(I) + abs(Q)) > thresh;
+		oI[o] = (int)(int16_t)si;
+		oQ[o] = (int)(int16_t)sq;
+		outw[o] = ((uint32_t)oI[o] & 0xffffu) | ((uint32_t)oQ[o] << 16);
+		trig[o] = (abs(oI[o]) + abs(oQ[o])) > thresh;
 	}
 	*reinterpret_cast<uint4 *>(dec + (size_t)s * dec_stride + m0 + 4 * tid) =
 		make_uint4(outw[0], outw[1], outw[2], outw[3]);
@@ -148,16 +152,55 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 					     (spread4((b2 >> sh) & 0xffff) << 2) | (spread4((b3 >> sh) & 0xffff) << 3);
 		mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + lane] = w;
 	}
+
+	// ---- FM discriminator of every decimated sample against its predecessor (fm_dev, dsp_stuff.cpp:284-292):
+	// the fp64 atan2 is a pure map, so it runs here in parallel instead of inside the serial demodulator
+	// chains; TFA_2, TFA_3 and TX22 (tfa2.cpp:361) all consume this one array.
+	lastw[tid] = outw[3];
+	int pI, pQ;
+	if (tid == 0) {
+		// previous decimated sample y2[m0-1] (for m0 == 0 it comes out of the carried raw history,
+		// i.e. the last decimated sample of the previous submit; zero history at stream start)
+		int si = 0, sq = 0;
+#pragma unroll
+		for (int n = 0; n < 20; n++) {
+			si += mulhi24(taps.s2[n], y1i[2 + n]);
+			sq += mulhi24(taps.s2[n], y1q[2 + n]);
+		}
+		pI = (int)(int16_t)si;
+		pQ = (int)(int16_t)sq;
+	}
+	__syncthreads();
+	if (tid != 0) {
+		const uint32_t pw = lastw[tid - 1];
+		pI = (int)(int16_t)(pw & 0xffff);
+		pQ = (int)pw >> 16;
+	}
+	int dv[4];
+	unsigned n_unc = 0;
+#pragma unroll
+	for (int o = 0; o < 4; o++) {
+		bool unc;
+		dv[o] = fm_dev(oI[o], oQ[o], pI, pQ, &unc);
+		n_unc += unc ? 1u : 0u;
+		pI = oI[o];
+		pQ = oQ[o];
+	}
+	if (n_unc)
+		atomicAdd(&eb->uncertain, (unsigned long long)n_unc);
+	*reinterpret_cast<uint2 *>(fmdev + (size_t)s * fmdev_stride + m0 + 4 * tid) =
+		make_uint2(((uint32_t)dv[0] & 0xffffu) | ((uint32_t)dv[1] << 16), ((uint32_t)dv[2] & 0xffffu) | ((uint32_t)dv[3] << 16));
 }
 
 hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
-			   unsigned long long *mask, size_t mask_stride, int thresh, const FrontTaps &taps)
+			   unsigned long long *mask, size_t mask_stride, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
+			   int thresh, const FrontTaps &taps)
 {
 	const int m_total = n_blocks * kBlockDec;
 	dim3 grid(m_total / kTileDec, n_streams);
 	hipLaunchKernelGGL(frontend_kernel, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out, dec,
-			   dec_stride, mask, mask_stride, thresh, taps);
+			   dec_stride, mask, mask_stride, fmdev, fmdev_stride, eb, thresh, taps);
 	return hipGetLastError();
 }
 

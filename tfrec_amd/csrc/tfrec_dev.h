@@ -11,15 +11,16 @@ namespace tfrec {
 
 constexpr int kBlockDec = TFREC_AMD_BLOCK_DEC;  // 8192 decimated pairs per reference block
 constexpr int kIndexSpan = 2 * kBlockDec;       // 'len' of fsk_demod::process / demodulator::start (fm_demod.cpp:38-40)
-constexpr int kTailBytes = 96;                  // raw bytes of FIR history carried between submits (48 complex samples
-                                                // >= the 46-sample halo of the 8+20 tap cascade, dsp_stuff.cpp:172-230)
+constexpr int kTailBytes = 112;                 // raw bytes of history carried between submits: 56 complex samples >= the
+                                                // 46-sample halo of the 8+20 tap cascade (dsp_stuff.cpp:172-230) + 4 for
+                                                // the previous decimated sample the discriminator needs, 16-byte multiple
 constexpr int kNSlots = TFREC_AMD_NSLOTS;
 
 // ---- front-end tile geometry
 constexpr int kTileDec = 1024;                       // decimated outputs per workgroup tile
 constexpr int kFrontThreads = 256;
 constexpr int kRawChunks = (kTailBytes + 8 * kTileDec + 16 + 15) / 16;  // 16-byte chunks staged per tile
-constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per channel (need 2*T+18)
+constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per channel (need 2*T+24)
 
 // Second-stage taps, pre-shifted by 8 for v_mul_hi_i32_i24 (see frontend.hip).
 struct FrontTaps {
@@ -81,6 +82,42 @@ struct EventBuf {
 	uint32_t capacity;
 	unsigned long long uncertain;  // fm_dev results within 1e-9 of a truncation boundary
 };
+
+// ---- window-parallel pipeline (chains2.hip)
+
+// Result of running one trigger window of a TFA_1 / TFA_2-family demodulator (one lane per window).
+struct WinResult {
+	int32_t nbits;         // bits written to the window's bit region
+	int32_t closed;        // the window's flush fired inside this submit
+	int32_t rssi_i;        // raw rssi at flush (or so far, if the window is still open)
+	int32_t offset;        // tfa2 offset at flush (or so far)
+	int32_t lbi_out;       // last_bit_idx after the window, relative to the block of its last sample
+	int32_t first_cand_g;  // tfa2: first sample whose slicer saw a candidate edge (-1: none) -- speculation check
+	int32_t bitcnt, dmin, dmax, last_bit, mark_lvl;  // slicer state (needed when the window stays open)
+	int32_t pad_;
+};
+
+struct WorkQueue {
+	uint32_t count;  // items pushed
+	uint32_t head;   // items taken
+};
+
+struct WinTables {
+	int32_t cap;            // windows per chain the tables can hold
+	int32_t bit_words;      // 32-bit words of bit storage per chain
+	int32_t *count;         // [chains] windows found in this submit
+	int32_t *cont;          // [chains] window 0 continues a window left open by the previous submit
+	int32_t *timeout_next;  // [chains] timeout_cnt after the last sample of this submit
+	int32_t *open;          // [chains*cap] first sample of the window
+	int32_t *close;         // [chains*cap] sample at which the window's flush fires (>= M: after this submit)
+	WinResult *result;      // [chains*cap]
+	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
+	uint2 *items;           // [4][chains*cap] work items (chain, j); queue 2*kind + {0: long, 1: short windows}
+	WorkQueue *queue;       // [4]
+	int32_t *overflow;      // set when a chain found more than cap windows
+};
+
+constexpr int kLongWindow = 6000;  // samples; longer windows are handed out first (tail balance)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
 static_assert(offsetof(tfrec_amd_event, rdata) == 32, "event rdata offset");
