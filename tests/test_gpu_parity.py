@@ -128,3 +128,41 @@ def test_device_resident_input_and_timings():
         assert t["frontend_ms"] > 0 and t["chains_ms"] > 0
         for s in range(n_streams):
             check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
+
+
+def _stress_batch():
+    """Inputs that open and close trigger windows as often as possible (noise hovering around the threshold),
+    saturate them (uniform random bytes), or pack bursts tightly: exercises window tables at their limits,
+    the tfa2 last_bit_idx speculation repair, biquad convergence failures and block-boundary corner cases."""
+    rng = np.random.default_rng(5)
+    n_blocks = 12
+    rows = []
+    for k, (noise, mask) in enumerate([(2048, 0x1F), (1536, 0x1F), (1024, 0x1F), (768, 0x0E), (3072, 0x00), (2560, 0x11)]):
+        rows.append(synth.gen_stream(77, k, n_blocks, mask, noise))
+    rows.append(rng.integers(0, 256, n_blocks * 65536, dtype=np.uint8))           # always triggered
+    r = rng.integers(0, 256, n_blocks * 65536, dtype=np.uint8)
+    gate = (np.arange(r.size) // 3000) % 2 == 0                                     # on/off every 1500 samples
+    rows.append(np.where(gate, r, 128).astype(np.uint8))
+    gate2 = (np.arange(r.size) // 1700) % 3 == 0
+    rows.append(np.where(gate2, r, (128 + rng.integers(-2, 3, r.size))).astype(np.uint8))
+    return np.stack(rows)
+
+
+@SERIAL
+@pytest.mark.parametrize("thresh", [350, 500, 900])
+def test_stress_sporadic_triggers(serial, thresh):
+    iq = _stress_batch()
+    n_streams, n_blocks = iq.shape[0], iq.shape[1] // 65536
+    with api.Receiver(n_streams, 0x2F, thresh, 0, max_blocks=n_blocks, all_flushes=True, serial_chains=serial,
+                      max_events=400000) as r:
+        # two submits so that windows straddle the submit boundary as well
+        r.submit(np.ascontiguousarray(iq[:, : 5 * 65536]))
+        e1 = r.drain()
+        r.submit(np.ascontiguousarray(iq[:, 5 * 65536:]))
+        e2 = r.drain()
+        ev = np.concatenate([e1, e2])
+        ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
+        total = 0
+        for s in range(n_streams):
+            total += check_stream(ev, s, oracle_events(iq[s], 0x2F, thresh))
+        assert total > 500

@@ -260,20 +260,21 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	}
 	c->dec_stride = m_max;
 	c->mask_stride = m_max / 64;
-	ALLOC(c->d_dec, n * c->dec_stride * sizeof(uint32_t));
+	ALLOC(c->d_dec, n * c->dec_stride * sizeof(uint32_t) + 256);  // + slack: K3 loads whole 32-sample chunks at window tails
 	ALLOC(c->d_mask, n * c->mask_stride * sizeof(unsigned long long));
-	ALLOC(c->d_fmdev, n * m_max * sizeof(int16_t));
+	ALLOC(c->d_fmdev, n * m_max * sizeof(int16_t) + 256);  // + slack: K3 reads whole dwords past an odd tail
 	if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
 		// window-parallel pipeline buffers (chains2.hip)
 		const size_t chains = (size_t)c->launch.n_active * n;
 		bool whb = false;
 		for (int a = 0; a < c->launch.n_active; a++)
 			whb = whb || c->launch.params[a].kind == 2;
-		ALLOC(c->d_ld16, chains * m_max * sizeof(int16_t));
-		if (whb)
-			ALLOC(c->d_dev32, n * m_max * sizeof(int32_t));
 		WinTables &T = c->win;
 		T.cap = (int32_t)(m_max / 356 + 2);  // windows of one chain are > W-1 >= 355 samples apart
+		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
+		ALLOC(c->d_ld16, chains * (size_t)T.slots * 32 * sizeof(int16_t));
+		if (whb)
+			ALLOC(c->d_dev32, n * (size_t)T.slots * 32 * sizeof(int32_t));
 		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
 		const size_t wins = chains * (size_t)T.cap;
 		size_t off = 0;
@@ -284,8 +285,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		};
 		const size_t o_count = carve(chains * 4), o_cont = carve(chains * 4), o_tnext = carve(chains * 4);
 		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
-		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve(4 * wins * sizeof(uint2));
-		const size_t o_queue = carve(4 * sizeof(WorkQueue)), o_ovf = carve(4);
+		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve(kNQueues * wins * sizeof(uint2));
+		const size_t o_queue = carve(kNQueues * sizeof(WorkQueue)), o_ovf = carve(4);
+		const size_t o_ckpt = carve(chains * (size_t)T.slots * sizeof(double2)), o_wend = carve(wins * sizeof(BiquadEnd));
+		const size_t o_pw = carve(n * (size_t)T.slots * 8);
 		ALLOC(c->win_block, off);
 		if (rc == TFREC_AMD_OK) {
 			uint8_t *b = (uint8_t *)c->win_block;
@@ -299,7 +302,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.items = (uint2 *)(b + o_items);
 			T.queue = (WorkQueue *)(b + o_queue);
 			T.overflow = (int32_t *)(b + o_ovf);
-			if (hipMemset(T.queue, 0, 4 * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess)
+			T.ckpt = (double2 *)(b + o_ckpt);
+			T.wend = (BiquadEnd *)(b + o_wend);
+			T.pw = (unsigned long long *)(b + o_pw);
+			if (hipMemset(T.queue, 0, kNQueues * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
 	}

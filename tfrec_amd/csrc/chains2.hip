@@ -88,6 +88,12 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 				const uint32_t idx = atomicAdd(&T.queue[q].count, 1u);
 				T.items[(size_t)q * total + idx] = make_uint2((uint32_t)c, (uint32_t)count);
 			}
+			if (p.kind > 0) {  // the chain owns a biquad: speculative window run (K3a)
+				const int last = close < M ? close : M - 1;
+				const int q = 2 + 2 * p.kind + ((last - og + 1) >= kLongWindow ? 0 : 1);  // 4,5: TFA_2 family; 6,7: WHB
+				const uint32_t idx = atomicAdd(&T.queue[q].count, 1u);
+				T.items[(size_t)q * total + idx] = make_uint2((uint32_t)c, (uint32_t)count);
+			}
 			count++;
 		} else
 			overflow = true;
@@ -175,145 +181,269 @@ struct ChunkIter {
 };
 
 // ------------------------------------------------------------------------------------------------ K3
-// One lane = one biquad chain; double-buffered 32-sample chunks in registers (the loads of chunk n+1 are in
-// flight while chunk n is filtered), fully unrolled predicated steps.
-__device__ __forceinline__ void k3_load16(const int16_t *row, const ChunkDesc &d, uint4 (&b)[4])
+// The fp64 biquads (iir2::step) are the one recurrence whose state crosses windows.  They are strongly
+// contracting (pole radius 0.87-0.95): a window started from the WRONG state becomes bit-identical to the true
+// trajectory after a few hundred samples, and once the full state (yn, yn1 + the two last inputs) matches
+// bit for bit it matches forever.  So:
+//   K3a spec_biquad_kernel  lane per WINDOW (work queue): runs every window from a zero state (window 0 of a
+//                           chain from the true carried state), stores the truncated outputs the slicers
+//                           consume, a (yn, yn1) checkpoint per 32 samples and the end state;
+//   K3b fix_biquad_kernel   lane per CHAIN: walks the windows in order from the true state, recomputing each
+//                           window's head until its state equals the speculative checkpoint bit for bit --
+//                           from there on the speculative outputs ARE the exact ones.  A window that never
+//                           converges is simply recomputed to its end.  Exactness never depends on convergence.
+// Outputs are window-relative: window j of a chain owns the 32-sample slots (open>>5)+j ... so every chunk is
+// full except a window's tail, and tails may be stored whole.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load, dword aligned
+
+__device__ __forceinline__ int win_slot0(int og, int j) { return (og >> 5) + j; }
+
+// iir2::step without the range check of d2i: |y| <= 1.0911 * max|x| (L1 norm of the impulse responses), so the
+// tfa2 outputs stay below 17 877 and the WHB stage-1 outputs below 1.3e9: v_cvt_i32_f64 truncates exactly.
+__device__ __forceinline__ int iir_step_i(Biquad &f, const BiquadCoef &c, int x) { return (int)iir_step(f, c, (double)x); }
+
+template <bool WHB>
+struct K3Chunk {
+	uint32_t w[WHB ? 32 : 17];
+	uint32_t prevw;  // WHB: decimated sample before the chunk
+};
+
+template <bool WHB>
+__device__ __forceinline__ void k3_load(K3Chunk<WHB> &ch, const void *row, int g0, uint32_t prev0)
 {
-	const uint4 *p = reinterpret_cast<const uint4 *>(row + d.cb);
+	if (WHB) {
+		const uint32_t *drow = static_cast<const uint32_t *>(row);
+		const u32x4_a4 *p = reinterpret_cast<const u32x4_a4 *>(drow + g0);
 #pragma unroll
-	for (int i = 0; i < 4; i++)
-		b[i] = p[i];
+		for (int i = 0; i < 8; i++) {
+			const u32x4_a4 v = p[i];
+			ch.w[4 * i] = v.x; ch.w[4 * i + 1] = v.y; ch.w[4 * i + 2] = v.z; ch.w[4 * i + 3] = v.w;
+		}
+		ch.prevw = g0 > 0 ? drow[g0 - 1] : prev0;
+	} else {
+		const int16_t *in = static_cast<const int16_t *>(row);
+		const uint32_t *base = reinterpret_cast<const uint32_t *>(in + (g0 & ~1));
+		const u32x4_a4 *p = reinterpret_cast<const u32x4_a4 *>(base);
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const u32x4_a4 v = p[i];
+			ch.w[4 * i] = v.x; ch.w[4 * i + 1] = v.y; ch.w[4 * i + 2] = v.z; ch.w[4 * i + 3] = v.w;
+		}
+		ch.w[16] = base[16];
+		if (g0 & 1) {  // odd start: shift the 17 dwords down by one int16
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				ch.w[i] = (ch.w[i] >> 16) | (ch.w[i + 1] << 16);
+		}
+	}
 }
 
-__device__ __forceinline__ void k3_proc16(Biquad &f, const BiquadCoef &cf, const ChunkDesc &d, const uint4 (&b)[4],
-					  int16_t *out)
+// Filter `nvalid` samples of a chunk (groups of 8: unpredicated while the whole group is valid).
+template <bool WHB>
+__device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const K3Chunk<WHB> &ch, int nvalid,
+					  uint32_t (&ow)[WHB ? 32 : 16], unsigned long long &pw)
 {
-	const bool full = (d.lo == d.cb) && (d.hi == d.cb + kChunk - 1);
-	uint32_t ow[16];
+	int pI = (int)(int16_t)(ch.prevw & 0xffff), pQ = (int)ch.prevw >> 16;
 #pragma unroll
-	for (int i = 0; i < 16; i++)
+	for (int i = 0; i < (WHB ? 32 : 16); i++)
 		ow[i] = 0;
 #pragma unroll
-	for (int k = 0; k < kChunk; k++) {
-		const int gk = d.cb + k;
-		const uint4 &q = b[k >> 3];
-		const uint32_t w = ((k >> 1) & 3) == 0 ? q.x : ((k >> 1) & 3) == 1 ? q.y : ((k >> 1) & 3) == 2 ? q.z : q.w;
-		if (gk >= d.lo && gk <= d.hi) {
-			const int x = (int)(int16_t)((w >> (16 * (k & 1))) & 0xffff);
-			const int y = d2i(iir_step(f, cf, (double)x));
-			ow[k >> 1] |= ((uint32_t)y & 0xffffu) << (16 * (k & 1));
-			if (!full)
-				out[gk] = (int16_t)y;
+	for (int grp = 0; grp < 4; grp++) {
+		auto one = [&](int k) {
+			int y;
+			if (WHB) {
+				const int I = (int)(int16_t)(ch.w[k] & 0xffff), Q = (int)ch.w[k] >> 16;
+				y = iir_step_i(f, cf, fm_dev_nrzs(I, Q, pI, pQ));  // whb.cpp:651-652
+				pw += (unsigned long long)(uint32_t)(I * I + Q * Q);
+				pI = I;
+				pQ = Q;
+				ow[k] = (uint32_t)y;
+			} else {
+				const int x = (int)(int16_t)((ch.w[k >> 1] >> (16 * (k & 1))) & 0xffff);
+				y = iir_step_i(f, cf, x);  // tfa2.cpp:362
+				ow[k >> 1] |= ((uint32_t)y & 0xffffu) << (16 * (k & 1));
+			}
+		};
+		if (nvalid >= 8 * (grp + 1)) {
+#pragma unroll
+			for (int k = 8 * grp; k < 8 * grp + 8; k++)
+				one(k);
+		} else if (nvalid > 8 * grp) {
+#pragma unroll
+			for (int k = 8 * grp; k < 8 * grp + 8; k++)
+				if (k < nvalid)
+					one(k);
 		}
 	}
-	if (full) {
-		uint4 *o = reinterpret_cast<uint4 *>(out + d.cb);
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-			o[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
-	}
 }
 
-__device__ __forceinline__ void k3_load32(const uint32_t *drow, const ChunkDesc &d, uint4 (&b)[8], uint32_t &prevw,
-					  uint32_t prev0)
+template <bool WHB>
+__device__ __forceinline__ void k3_store(void *outrow, int slot, const uint32_t (&ow)[WHB ? 32 : 16])
 {
-	const uint4 *p = reinterpret_cast<const uint4 *>(drow + d.cb);
+	uint4 *o = reinterpret_cast<uint4 *>(static_cast<uint32_t *>(outrow) + (size_t)slot * (WHB ? 32 : 16));
 #pragma unroll
-	for (int i = 0; i < 8; i++)
-		b[i] = p[i];
-	prevw = d.cb > 0 ? drow[d.cb - 1] : prev0;
+	for (int i = 0; i < (WHB ? 8 : 4); i++)
+		o[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
 }
 
-__device__ __forceinline__ void k3_proc32(Biquad &f, const BiquadCoef &cf, const ChunkDesc &d, const uint4 (&b)[8],
-					  uint32_t prevw, int32_t *out)
+template <bool WHB>
+__device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
+					    size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
+					    const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
+					    int32_t *__restrict__ dev32)
 {
-	const bool full = (d.lo == d.cb) && (d.hi == d.cb + kChunk - 1);
-	int pI = (int)(int16_t)(prevw & 0xffff), pQ = (int)prevw >> 16;
-	int ow[kChunk];
-#pragma unroll
-	for (int k = 0; k < kChunk; k++) {
-		const int gk = d.cb + k;
-		const uint4 &q = b[k >> 2];
-		const uint32_t w = (k & 3) == 0 ? q.x : (k & 3) == 1 ? q.y : (k & 3) == 2 ? q.z : q.w;
-		const int I = (int)(int16_t)(w & 0xffff), Q = (int)w >> 16;
-		ow[k] = 0;
-		if (gk >= d.lo && gk <= d.hi) {
-			// WHB stage 1: dev = (int) iir->step(fm_dev_nrzs(iq, last_iq)), whb.cpp:651-652
-			ow[k] = d2i(iir_step(f, cf, (double)fm_dev_nrzs(I, Q, pI, pQ)));
-			if (!full)
-				out[gk] = ow[k];
+	const int a = c / n_streams, s = c - a * n_streams;
+	const ChainParams &p = L.params[a];
+	const ChainState &st = L.states[a][s];
+	const int og = T.open[(size_t)c * T.cap + j];
+	const int close = T.close[(size_t)c * T.cap + j];
+	const int n = (close < M ? close : M - 1) - og + 1;
+	const BiquadCoef cf = p.iir;
+	Biquad f;
+	if (j == 0)
+		f = st.iir;  // the chain's first window starts from the true carried state
+	else
+		f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
+	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
+	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
+	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
+	const int slot0 = win_slot0(og, j);
+	const int nchunks = (n + kChunk - 1) >> 5;
+	unsigned long long pw = 0;
+	K3Chunk<WHB> A, B;
+	k3_load<WHB>(A, in, og, prev0);
+	for (int i = 0; i < nchunks; i += 2) {
+		if (i + 1 < nchunks)
+			k3_load<WHB>(B, in, og + kChunk * (i + 1), prev0);
+		{
+			uint32_t ow[WHB ? 32 : 16];
+			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+			k3_filter<WHB>(f, cf, A, nv, ow, pw);
+			k3_store<WHB>(out, slot0 + i, ow);
+			T.ckpt[(size_t)c * T.slots + slot0 + i] = make_double2(f.yn, f.yn1);
+			if (WHB)
+				T.pw[(size_t)s * T.slots + slot0 + i] = pw;
 		}
-		pI = I;
-		pQ = Q;
+		if (i + 1 >= nchunks)
+			break;
+		if (i + 2 < nchunks)
+			k3_load<WHB>(A, in, og + kChunk * (i + 2), prev0);
+		{
+			uint32_t ow[WHB ? 32 : 16];
+			const int nv = n - kChunk * (i + 1) < kChunk ? n - kChunk * (i + 1) : kChunk;
+			k3_filter<WHB>(f, cf, B, nv, ow, pw);
+			k3_store<WHB>(out, slot0 + i + 1, ow);
+			T.ckpt[(size_t)c * T.slots + slot0 + i + 1] = make_double2(f.yn, f.yn1);
+			if (WHB)
+				T.pw[(size_t)s * T.slots + slot0 + i + 1] = pw;
+		}
 	}
-	if (full) {
-		int4 *o = reinterpret_cast<int4 *>(out + d.cb);
-#pragma unroll
-		for (int i = 0; i < 8; i++)
-			o[i] = make_int4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+	BiquadEnd &we = T.wend[(size_t)c * T.cap + j];
+	we.dn1 = f.dn1;
+	we.dn2 = f.dn2;
+	we.yn = f.yn;
+	we.yn1 = f.yn1;
+}
+
+__global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
+							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
+							 int32_t *__restrict__ dev32)
+{
+	const int M = n_blocks * kBlockDec;
+	const size_t total = (size_t)L.n_active * n_streams * T.cap;
+	const int whb = blockIdx.y;  // a wave runs one kind of biquad window
+	for (int q = 4 + 2 * whb; q < 6 + 2 * whb; q++) {
+		const uint32_t count = T.queue[q].count;
+		while (true) {
+			const uint32_t idx = atomicAdd(&T.queue[q].head, 1u);
+			if (idx >= count)
+				break;
+			const uint2 it = T.items[(size_t)q * total + idx];
+			const int c = (int)it.x, j = (int)it.y;
+			if (whb)
+				spec_window<true>(c, j, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+			else
+				spec_window<false>(c, j, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+		}
 	}
 }
 
-__global__ __launch_bounds__(64) void biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
-						    const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
-						    int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-						    int32_t *__restrict__ dev32)
+template <bool WHB>
+__device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, const uint32_t *__restrict__ dec,
+					  size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
+					  const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
+					  int32_t *__restrict__ dev32)
+{
+	const int c = a * n_streams + s;
+	const ChainParams &p = L.params[a];
+	ChainState &st = L.states[a][s];
+	const int count = T.count[c];
+	if (count == 0)
+		return;
+	const BiquadCoef cf = p.iir;
+	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
+	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
+	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
+	BiquadEnd tr = T.wend[(size_t)c * T.cap];  // window 0 ran from the true state
+	Biquad f;
+	int j = 0, i = 0, nchunks = 0, og = 0, n = 0, slot0 = 0;
+	while (true) {
+		if (i >= nchunks) {
+			if (j > 0 && nchunks > 0) {  // window j ended without convergence: its true end state is ours
+				tr.dn1 = f.dn1; tr.dn2 = f.dn2; tr.yn = f.yn; tr.yn1 = f.yn1;
+				T.wend[(size_t)c * T.cap + j] = tr;
+			}
+			if (++j >= count)
+				break;
+			og = T.open[(size_t)c * T.cap + j];
+			const int close = T.close[(size_t)c * T.cap + j];
+			n = (close < M ? close : M - 1) - og + 1;
+			nchunks = (n + kChunk - 1) >> 5;
+			slot0 = win_slot0(og, j);
+			i = 0;
+			f.dn1 = tr.dn1; f.dn2 = tr.dn2; f.yn = tr.yn; f.yn1 = tr.yn1;
+		}
+		K3Chunk<WHB> A;
+		k3_load<WHB>(A, in, og + kChunk * i, prev0);
+		const double2 ck = T.ckpt[(size_t)c * T.slots + slot0 + i];
+		uint32_t ow[WHB ? 32 : 16];
+		unsigned long long pw_unused = 0;
+		const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+		k3_filter<WHB>(f, cf, A, nv, ow, pw_unused);
+		k3_store<WHB>(out, slot0 + i, ow);
+		// bit-for-bit state match with the speculative run?  (the two last inputs are shared once 2 samples in)
+		const bool same = __double_as_longlong(f.yn) == __double_as_longlong(ck.x) &&
+				  __double_as_longlong(f.yn1) == __double_as_longlong(ck.y) && (kChunk * i + nv) >= 2;
+		if (same) {
+			tr = T.wend[(size_t)c * T.cap + j];  // the rest of the speculative run is exact
+			nchunks = 0;                         // -> next window, without the "not converged" path
+			i = 0;
+		} else {
+			i++;
+		}
+	}
+	st.iir.dn1 = tr.dn1;
+	st.iir.dn2 = tr.dn2;
+	st.iir.yn = tr.yn;
+	st.iir.yn1 = tr.yn1;
+}
+
+__global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+							const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
+							int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
+							int32_t *__restrict__ dev32)
 {
 	const int a = blockIdx.y;
 	const int s = blockIdx.x * 64 + threadIdx.x;
-	const ChainParams &p = L.params[a];
-	if (s >= n_streams || p.kind == 0)
+	if (s >= n_streams)
 		return;
-	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
-	ChainState &st = L.states[a][s];
-	Biquad f = st.iir;
-	const BiquadCoef cf = p.iir;
-	ChunkIter it;
-	it.init(T, c, M);
-	ChunkDesc dA, dB;
-	if (p.kind == 1) {
-		const int16_t *in = fmdev + (size_t)s * fmdev_stride;
-		int16_t *out = ld16 + (size_t)c * M;
-		uint4 A[4], B[4];
-		bool hA = it.next(dA), hB;
-		if (hA)
-			k3_load16(in, dA, A);
-		while (hA) {
-			hB = it.next(dB);
-			if (hB)
-				k3_load16(in, dB, B);
-			k3_proc16(f, cf, dA, A, out);
-			if (!hB)
-				break;
-			hA = it.next(dA);
-			if (hA)
-				k3_load16(in, dA, A);
-			k3_proc16(f, cf, dB, B, out);
-		}
-	} else {
-		const uint32_t *drow = dec + (size_t)s * dec_stride;
-		int32_t *out = dev32 + (size_t)s * M;
-		const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
-		uint4 A[8], B[8];
-		uint32_t pA = 0, pB = 0;
-		bool hA = it.next(dA), hB;
-		if (hA)
-			k3_load32(drow, dA, A, pA, prev0);
-		while (hA) {
-			hB = it.next(dB);
-			if (hB)
-				k3_load32(drow, dB, B, pB, prev0);
-			k3_proc32(f, cf, dA, A, pA, out);
-			if (!hB)
-				break;
-			hA = it.next(dA);
-			if (hA)
-				k3_load32(drow, dA, A, pA, prev0);
-			k3_proc32(f, cf, dB, B, pB, out);
-		}
-	}
-	st.iir = f;
+	const int kind = L.params[a].kind;
+	if (kind == 1)
+		fix_chain<false>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+	else if (kind == 2)
+		fix_chain<true>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 }
 
 // ------------------------------------------------------------------------------------------------ slicers
@@ -419,13 +549,13 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 // out; bits go to bw.  Returns with f.cur_block = block of `last`.
 template <int KIND>
 __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int last, bool closed,
-					   const uint32_t *__restrict__ drow, const int16_t *__restrict__ ldrow, int prevI,
+					   const uint32_t *__restrict__ drow, const uint32_t *__restrict__ ldslots, int prevI,
 					   int prevQ, double spb)
 {
-	int g = g0;
-	while (g <= last) {
-		const int cb = g & ~7;
-		if (KIND == 0) {
+	if (KIND == 0) {
+		int g = g0;
+		while (g <= last) {
+			const int cb = g & ~7;
 			const uint4 v0 = *reinterpret_cast<const uint4 *>(drow + cb);
 			const uint4 v1 = *reinterpret_cast<const uint4 *>(drow + cb + 4);
 			const uint32_t vw[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
@@ -444,22 +574,25 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 				pI = I;
 				pQ = Q;
 			}
-		} else {
-			const uint4 v = *reinterpret_cast<const uint4 *>(ldrow + cb);
+			g = cb + 8;
+		}
+	} else {
+		// ld = biquad output, window-relative slots of 32 samples (K3)
+		const int n = last - g0 + 1;
+		for (int r0 = 0; r0 < n; r0 += 8) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(ldslots + (r0 >> 1));
 			const uint32_t vw[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 			for (int k = 0; k < 8; k++) {
-				const int gk = cb + k;
-				if (gk >= g && gk <= last) {
+				if (r0 + k < n) {
 					const int ld = (int)(int16_t)((vw[k >> 1] >> (16 * (k & 1))) & 0xffff);
-					tfa2_sample(f, bw, gk, ld, drow, spb);
+					tfa2_sample(f, bw, g0 + r0 + k, ld, drow, spb);
 				}
 			}
 		}
-		g = cb + 8;
 	}
 	const int bl = last >> 13;
-	if (bl != f.cur_block) {  // no sample processed in the last block?  cannot happen (last is processed), kept for safety
+	if (bl != f.cur_block) {
 		f.lbi = rebase_lbi(f.lbi, f.cur_block, bl);
 		f.cur_block = bl;
 	}
@@ -504,8 +637,10 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	}
 	BitWriter bw{ T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0u, 0 };
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const int16_t *ldrow = (KIND == 1) ? ld16 + (size_t)c * M : nullptr;
-	run_window<KIND>(f, bw, og, last, closed, drow, ldrow, st.prev_i, st.prev_q, p.spb);
+	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
+							(size_t)win_slot0(og, j) * 16
+					      : nullptr;
+	run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb);
 	bw.finish();
 	WinResult &r = T.result[(size_t)c * T.cap + j];
 	r.nbits = bw.n;
@@ -548,18 +683,52 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ K4' WHB stage 2
-// Serial lane per stream.  Per iteration: the current 32-sample chunk (stage-1 output + decimated IQ) is moved
-// from registers to a lane-private LDS column, the NEXT chunk's global loads are issued, then the chunk is
-// walked sample by sample from LDS -- so HBM latency overlaps the state machine instead of preceding it.
+// Serial lane per stream (demodulator and decoder feed back through has_sync(), whb.cpp:653/677/693).
+// Per 32-sample slot of stage-1 output: (1) a branch-free pass steps the decision-level biquad (only while the
+// decoder is unsynced) and collects the "local minimum below average" candidates (whb.cpp:662-663) in a bit
+// mask; (2) an event loop visits only the candidates that also satisfy the 3/4-bit spacing rule (:664), emits
+// their bits through the decoder, and -- if the decoder locks in the middle of a slot -- rewinds the slot to
+// that sample and redoes the rest in synced mode.  The RSSI sum of a synced interval (:678) is an exact
+// integer, so it is taken as a difference of the power prefix K3a stored per slot.
+struct WhbFast {
+	Biquad iir_avg;
+	int avg_of, last_dev;
+};
+
+template <bool PRED>
+__device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg, const uint32_t (&dv)[32], bool synced,
+					     int k0, int k1)
+{
+	uint32_t mask = 0;
+	if (!synced) {
+#pragma unroll
+		for (int k = 0; k < 32; k++) {
+			if (!PRED || (k >= k0 && k <= k1)) {
+				const int dev = (int)dv[k];
+				w.avg_of = d2i(iir_step(w.iir_avg, cavg, 0.5 * dev));  // whb.cpp:654
+				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << k;
+				w.last_dev = dev;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int k = 0; k < 32; k++) {
+			if (!PRED || (k >= k0 && k <= k1)) {
+				const int dev = (int)dv[k];
+				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << k;
+				w.last_dev = dev;
+			}
+		}
+	}
+	return mask;
+}
+
 __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						 const int32_t *__restrict__ dev32, int n_streams, int n_blocks, long long sample_base,
 						 ChainLaunch L, int a, WinTables T, tfrec_amd_event *__restrict__ events,
 						 EventBuf *__restrict__ eb, uint32_t flags)
 {
-	__shared__ uint32_t sdev[kChunk * 64];
-	__shared__ uint32_t sdec[kChunk * 64];
-	const int lane = threadIdx.x;
-	const int s = blockIdx.x * 64 + lane;
+	const int s = blockIdx.x * 64 + threadIdx.x;
 	if (s >= n_streams)
 		return;
 	const ChainParams &p = L.params[a];
@@ -567,85 +736,159 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const int32_t *dvrow = dev32 + (size_t)s * M;
+	const uint32_t *dvrow = reinterpret_cast<const uint32_t *>(dev32 + (size_t)s * T.slots * 32);
+	const unsigned long long *pwrow = T.pw + (size_t)s * T.slots;
 	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
 	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
 	       st.rdata };
-	int last_dev = st.last_dev, avg_of = st.avg_of;
-	unsigned long long step = st.step, last_peak = st.last_peak;
-	double rssi_d = st.rssi_d;
-	Biquad iir_avg = st.iir_avg;
+	WhbFast w{ st.iir_avg, st.avg_of, st.last_dev };
 	const BiquadCoef cavg = p.iir_avg;
 	const double spb = p.spb;
+	const double thr = 3 * spb / 4;             // whb.cpp:664
+	const int tmin = (int)floor(thr) + 1;       // smallest tdiff with tdiff > thr
+	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
+	double rssi_d = st.rssi_d;                  // rssi collected in earlier submits of a still-open window
+	unsigned long long rssi_base = 0;           // power prefix just before the first synced sample (this submit)
+	const int count = T.count[c];
 	const bool cont = T.cont[c] != 0;
 
-	ChunkIter it;
-	it.init(T, c, M);
-	ChunkDesc dC, dN;
-	uint4 rv[8], rd[8];
-	auto load = [&](const ChunkDesc &dd) {
-		const uint4 *pv = reinterpret_cast<const uint4 *>(dvrow + dd.cb);
-		const uint4 *pd = reinterpret_cast<const uint4 *>(drow + dd.cb);
+	// power prefix of the window up to and including sample r (window-relative), this submit
+	auto prefix_at = [&](int og, int slot0, int r) -> unsigned long long {
+		if (r < 0)
+			return 0ull;
+		unsigned long long v = (r >> 5) > 0 ? pwrow[slot0 + (r >> 5) - 1] : 0ull;
+		for (int q = r & ~31; q <= r; q++) {
+			const uint32_t cw = drow[og + q];
+			const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
+			v += (unsigned long long)(uint32_t)(I * I + Q * Q);
+		}
+		return v;
+	};
+
+	int j = -1, i = 0, nchunks = 0, og = 0, n = 0, slot0 = 0, closed = 0;
+	uint32_t dvA[32], dvB[32];
+	auto load = [&](uint32_t (&dv)[32], int slot) {
+		const uint4 *pv = reinterpret_cast<const uint4 *>(dvrow + (size_t)slot * 32);
 #pragma unroll
-		for (int i = 0; i < 8; i++) {
-			rv[i] = pv[i];
-			rd[i] = pd[i];
+		for (int q = 0; q < 8; q++) {
+			const uint4 v = pv[q];
+			dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
 		}
 	};
-	bool hC = it.next(dC);
-	if (hC)
-		load(dC);
-	while (hC) {
-#pragma unroll
-		for (int i = 0; i < 8; i++) {
-			sdev[(4 * i + 0) * 64 + lane] = rv[i].x;
-			sdev[(4 * i + 1) * 64 + lane] = rv[i].y;
-			sdev[(4 * i + 2) * 64 + lane] = rv[i].z;
-			sdev[(4 * i + 3) * 64 + lane] = rv[i].w;
-			sdec[(4 * i + 0) * 64 + lane] = rd[i].x;
-			sdec[(4 * i + 1) * 64 + lane] = rd[i].y;
-			sdec[(4 * i + 2) * 64 + lane] = rd[i].z;
-			sdec[(4 * i + 3) * 64 + lane] = rd[i].w;
+	// returns false when the chain has no more slots
+	auto advance = [&]() -> bool {
+		if (i + 1 < nchunks) {
+			i++;
+			return true;
 		}
-		const bool hN = it.next(dN);
-		if (hN)
-			load(dN);
-		if ((dC.flags & 1) && !(dC.j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
+		if (++j >= count)
+			return false;
+		og = T.open[(size_t)c * T.cap + j];
+		const int close = T.close[(size_t)c * T.cap + j];
+		closed = close < M;
+		n = (closed ? close : M - 1) - og + 1;
+		nchunks = (n + kChunk - 1) >> 5;
+		slot0 = win_slot0(og, j);
+		i = 0;
+		if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 			rssi_d = 0;
-			step = last_peak = 0;
+			step0 = 0;
+			last_peak = 0;
 		}
-		const int k1 = dC.hi - dC.cb;
-		for (int k = dC.lo - dC.cb; k <= k1; k++) {
-			const int dev = (int)sdev[k * 64 + lane];  // stage 1 (biquad_kernel)
-			if (!d.synced)
-				avg_of = d2i(iir_step(iir_avg, cavg, 0.5 * dev));
-			const int tdiff = (int)(step - last_peak);
-			if (dev < avg_of && dev > last_dev && (tdiff > 3 * spb / 4)) {  // phase change, whb.cpp:662-673
-				store_bit<2>(d, 0);
+		return true;
+	};
+	auto process = [&](const uint32_t (&dv)[32]) {
+		const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+		const long long base_step = step0 + (long long)kChunk * i;
+		int k0 = 0;
+		while (true) {
+			const WhbFast snap = w;
+			const bool was_synced = d.synced != 0;
+			uint32_t mask = whb_pass<true>(w, cavg, dv, was_synced, k0, nv - 1);
+			int flip_k = -1;
+			while (mask) {
+				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
+				if (kmin > 31)
+					break;
+				if (kmin > 0)
+					mask &= ~0u << (int)kmin;
+				if (!mask)
+					break;
+				const int k = __builtin_ctz(mask);
+				mask &= mask - 1;
+				const int tdiff = (int)(base_step + k - last_peak);
+				store_bit<2>(d, 0);  // whb.cpp:666-673
 				const int bit0 = d2i((tdiff + spb / 2) / spb);
-				for (int n = 1; n < bit0; n++)
+				for (int q = 1; q < bit0; q++)
 					store_bit<2>(d, 1);
-				last_peak = step;
+				last_peak = base_step + k;
+				if (!was_synced && d.synced) {  // the decoder locked at sample k
+					rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);  // rssi counts from sample k on (:677)
+					if (k < nv - 1)
+						flip_k = k;
+					break;
+				}
 			}
-			last_dev = dev;
-			if (d.synced) {
-				const uint32_t cw = sdec[k * 64 + lane];
-				const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
-				rssi_d += (double)(I * I + Q * Q);
-			}
-			if (k == k1 && (dC.flags & 4)) {  // timeout_cnt reached 0, whb.cpp:691-702
+			if (flip_k < 0)
+				break;
+			// rewind to the slot state at k0, redo [k0, flip_k] unsynced to get the state after flip_k,
+			// then continue with (flip_k, nv) in synced mode
+			w = snap;
+			(void)whb_pass<true>(w, cavg, dv, false, k0, flip_k);
+			k0 = flip_k + 1;
+		}
+		if (i == nchunks - 1) {  // last sample of the window in this submit
+			if (closed) {        // timeout_cnt reached 0, whb.cpp:691-702
 				if (d.synced) {
-					for (int n = 0; n < 16; n++)
+					for (int q = 0; q < 16; q++)
 						store_bit<2>(d, 0);
-					flush<2>(e, d, (long long)rssi_d, 0, dC.cb + k);
+					const unsigned long long tot = pwrow[slot0 + i];
+					flush<2>(e, d, (long long)(rssi_d + (double)(tot - rssi_base)), 0, og + n - 1);
 				}
 				rssi_d = 0;
-				step = last_peak = 0;
+				rssi_base = 0;
+				step0 = 0;
+				last_peak = 0;
+			} else {  // window continues in the next submit
+				if (d.synced)
+					rssi_d += (double)(pwrow[slot0 + i] - rssi_base);
+				rssi_base = 0;
+				step0 += n;
 			}
-			step++;
 		}
-		dC = dN;
-		hC = hN;
+	};
+	bool hA = advance(), hB;
+	if (hA)
+		load(dvA, slot0 + i);
+	while (hA) {
+		// peek the next slot for the prefetch without disturbing the current position
+		const int sj = j, si = i, snc = nchunks, sog = og, sn = n, ss0 = slot0, scl = closed;
+		const double srd = rssi_d;
+		const long long sst = step0, slp = last_peak;
+		hB = advance();
+		const int nslot = slot0 + i;
+		j = sj; i = si; nchunks = snc; og = sog; n = sn; slot0 = ss0; closed = scl;
+		rssi_d = srd; step0 = sst; last_peak = slp;
+		if (hB)
+			load(dvB, nslot);
+		process(dvA);
+		if (!hB)
+			break;
+		advance();
+		{
+			const int sj2 = j, si2 = i, snc2 = nchunks, sog2 = og, sn2 = n, ss02 = slot0, scl2 = closed;
+			const double srd2 = rssi_d;
+			const long long sst2 = step0, slp2 = last_peak;
+			hA = advance();
+			const int nslot2 = slot0 + i;
+			j = sj2; i = si2; nchunks = snc2; og = sog2; n = sn2; slot0 = ss02; closed = scl2;
+			rssi_d = srd2; step0 = sst2; last_peak = slp2;
+			if (hA)
+				load(dvA, nslot2);
+		}
+		process(dvB);
+		if (hA)
+			advance();
 	}
 	{
 		const uint32_t lw = drow[M - 1];
@@ -653,12 +896,12 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		st.prev_q = (int)lw >> 16;
 	}
 	st.timeout_cnt = T.timeout_next[c];
-	st.last_dev = last_dev;
-	st.avg_of = avg_of;
-	st.step = step;
-	st.last_peak = last_peak;
+	st.last_dev = w.last_dev;
+	st.avg_of = w.avg_of;
+	st.step = (unsigned long long)step0;
+	st.last_peak = (unsigned long long)last_peak;
 	st.rssi_d = rssi_d;
-	st.iir_avg = iir_avg;
+	st.iir_avg = w.iir_avg;
 	st.sr = d.sr;
 	st.sr_cnt = d.sr_cnt;
 	st.byte_cnt = d.byte_cnt;
@@ -791,13 +1034,15 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 {
 	if (L.n_active == 0)
 		return hipSuccess;
-	hipError_t e = hipMemsetAsync(T.queue, 0, 4 * sizeof(WorkQueue), st);
+	hipError_t e = hipMemsetAsync(T.queue, 0, kNQueues * sizeof(WorkQueue), st);
 	if (e != hipSuccess)
 		return e;
 	dim3 grid((n_streams + 63) / 64, L.n_active), block(64);
 	hipLaunchKernelGGL(windows_kernel, grid, block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
-	hipLaunchKernelGGL(biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks, L, T,
-			   ld16, dev32);
+	hipLaunchKernelGGL(spec_biquad_kernel, dim3(2 * slicer_waves, 2), block, 0, st, dec, dec_stride, fmdev, fmdev_stride,
+			   n_streams, n_blocks, L, T, ld16, dev32);
+	hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks, L,
+			   T, ld16, dev32);
 	hipLaunchKernelGGL(slicer_kernel, dim3(slicer_waves, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T);
 	for (int a = 0; a < L.n_active; a++)
 		if (L.params[a].kind == 2)

@@ -97,6 +97,11 @@ struct WinResult {
 	int32_t pad_;
 };
 
+// full biquad state at the end of a window (speculative or repaired run)
+struct BiquadEnd {
+	double dn1, dn2, yn, yn1;
+};
+
 struct WorkQueue {
 	uint32_t count;  // items pushed
 	uint32_t head;   // items taken
@@ -112,11 +117,17 @@ struct WinTables {
 	int32_t *close;         // [chains*cap] sample at which the window's flush fires (>= M: after this submit)
 	WinResult *result;      // [chains*cap]
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
-	uint2 *items;           // [4][chains*cap] work items (chain, j); queue 2*kind + {0: long, 1: short windows}
-	WorkQueue *queue;       // [4]
+	uint2 *items;           // [8][chains*cap] work items (chain, j); slicer queues 2*kind + {0: long, 1: short windows},
+	                        // queues 4,5 (TFA_2 family) and 6,7 (WHB): windows of chains that own a biquad (long, short)
+	WorkQueue *queue;       // [8]
+	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
+	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
+	BiquadEnd *wend;        // [chains*cap] biquad state after the window's last sample of this submit
+	unsigned long long *pw; // [n_streams*slots] WHB: sum of I^2+Q^2 from the window's first sample to the slot's end
 	int32_t *overflow;      // set when a chain found more than cap windows
 };
 
+constexpr int kNQueues = 8;
 constexpr int kLongWindow = 6000;  // samples; longer windows are handed out first (tail balance)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
