@@ -695,29 +695,32 @@ struct WhbFast {
 	int avg_of, last_dev;
 };
 
+// One pass over samples [k0, k1] of a slot.  PRED = false: the whole slot (no per-sample tests).
+// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09, so (int) never saturates.
 template <bool PRED>
 __device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg, const uint32_t (&dv)[32], bool synced,
 					     int k0, int k1)
 {
-	uint32_t mask = 0;
+	int avg[32];
 	if (!synced) {
 #pragma unroll
 		for (int k = 0; k < 32; k++) {
-			if (!PRED || (k >= k0 && k <= k1)) {
-				const int dev = (int)dv[k];
-				w.avg_of = d2i(iir_step(w.iir_avg, cavg, 0.5 * dev));  // whb.cpp:654
-				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << k;
-				w.last_dev = dev;
-			}
+			if (!PRED || (k >= k0 && k <= k1))
+				w.avg_of = (int)iir_step(w.iir_avg, cavg, 0.5 * (double)(int)dv[k]);  // whb.cpp:653-654
+			avg[k] = w.avg_of;
 		}
 	} else {
 #pragma unroll
-		for (int k = 0; k < 32; k++) {
-			if (!PRED || (k >= k0 && k <= k1)) {
-				const int dev = (int)dv[k];
-				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << k;
-				w.last_dev = dev;
-			}
+		for (int k = 0; k < 32; k++)
+			avg[k] = w.avg_of;
+	}
+	uint32_t mask = 0;
+#pragma unroll
+	for (int k = 0; k < 32; k++) {
+		if (!PRED || (k >= k0 && k <= k1)) {
+			const int dev = (int)dv[k];
+			mask |= (uint32_t)(dev < avg[k] && dev > w.last_dev) << k;  // whb.cpp:662-663
+			w.last_dev = dev;
 		}
 	}
 	return mask;
@@ -744,15 +747,15 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 	WhbFast w{ st.iir_avg, st.avg_of, st.last_dev };
 	const BiquadCoef cavg = p.iir_avg;
 	const double spb = p.spb;
-	const double thr = 3 * spb / 4;             // whb.cpp:664
-	const int tmin = (int)floor(thr) + 1;       // smallest tdiff with tdiff > thr
+	const double thr = 3 * spb / 4;        // whb.cpp:664
+	const int tmin = (int)floor(thr) + 1;  // smallest integer tdiff with tdiff > thr
 	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
-	double rssi_d = st.rssi_d;                  // rssi collected in earlier submits of a still-open window
-	unsigned long long rssi_base = 0;           // power prefix just before the first synced sample (this submit)
+	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
+	unsigned long long rssi_base = 0;      // power prefix just before the first synced sample (this submit)
 	const int count = T.count[c];
 	const bool cont = T.cont[c] != 0;
 
-	// power prefix of the window up to and including sample r (window-relative), this submit
+	// power prefix of the window up to and including window-relative sample r (this submit)
 	auto prefix_at = [&](int og, int slot0, int r) -> unsigned long long {
 		if (r < 0)
 			return 0ull;
@@ -764,9 +767,6 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		}
 		return v;
 	};
-
-	int j = -1, i = 0, nchunks = 0, og = 0, n = 0, slot0 = 0, closed = 0;
-	uint32_t dvA[32], dvB[32];
 	auto load = [&](uint32_t (&dv)[32], int slot) {
 		const uint4 *pv = reinterpret_cast<const uint4 *>(dvrow + (size_t)slot * 32);
 #pragma unroll
@@ -775,36 +775,37 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 			dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
 		}
 	};
-	// returns false when the chain has no more slots
-	auto advance = [&]() -> bool {
-		if (i + 1 < nchunks) {
-			i++;
-			return true;
+
+	int j = -1, i = 0, nch = 0, og = 0, n = 0, slot0 = 0, closed = 0;
+	uint32_t cur[32], nxt[32];
+	while (true) {
+		if (i >= nch) {  // next window (21 per second of signal: its first slot is not prefetched)
+			if (++j >= count)
+				break;
+			og = T.open[(size_t)c * T.cap + j];
+			const int close = T.close[(size_t)c * T.cap + j];
+			closed = close < M;
+			n = (closed ? close : M - 1) - og + 1;
+			nch = (n + kChunk - 1) >> 5;
+			slot0 = win_slot0(og, j);
+			i = 0;
+			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
+				rssi_d = 0;
+				step0 = 0;
+				last_peak = 0;
+			}
+			load(cur, slot0);
 		}
-		if (++j >= count)
-			return false;
-		og = T.open[(size_t)c * T.cap + j];
-		const int close = T.close[(size_t)c * T.cap + j];
-		closed = close < M;
-		n = (closed ? close : M - 1) - og + 1;
-		nchunks = (n + kChunk - 1) >> 5;
-		slot0 = win_slot0(og, j);
-		i = 0;
-		if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
-			rssi_d = 0;
-			step0 = 0;
-			last_peak = 0;
-		}
-		return true;
-	};
-	auto process = [&](const uint32_t (&dv)[32]) {
+		if (i + 1 < nch)
+			load(nxt, slot0 + i + 1);  // in flight while this slot is processed
 		const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
 		const long long base_step = step0 + (long long)kChunk * i;
 		int k0 = 0;
 		while (true) {
 			const WhbFast snap = w;
 			const bool was_synced = d.synced != 0;
-			uint32_t mask = whb_pass<true>(w, cavg, dv, was_synced, k0, nv - 1);
+			uint32_t mask = (k0 == 0 && nv == kChunk) ? whb_pass<false>(w, cavg, cur, was_synced, 0, 31)
+								  : whb_pass<true>(w, cavg, cur, was_synced, k0, nv - 1);
 			int flip_k = -1;
 			while (mask) {
 				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
@@ -822,8 +823,8 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 				for (int q = 1; q < bit0; q++)
 					store_bit<2>(d, 1);
 				last_peak = base_step + k;
-				if (!was_synced && d.synced) {  // the decoder locked at sample k
-					rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);  // rssi counts from sample k on (:677)
+				if (!was_synced && d.synced) {  // the decoder locked at sample k: rssi counts from k on (:677)
+					rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);
 					if (k < nv - 1)
 						flip_k = k;
 					break;
@@ -831,14 +832,14 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 			}
 			if (flip_k < 0)
 				break;
-			// rewind to the slot state at k0, redo [k0, flip_k] unsynced to get the state after flip_k,
-			// then continue with (flip_k, nv) in synced mode
+			// rewind to the state at k0, redo [k0, flip_k] unsynced to get the state after flip_k, then go on
+			// with (flip_k, nv) in synced mode
 			w = snap;
-			(void)whb_pass<true>(w, cavg, dv, false, k0, flip_k);
+			(void)whb_pass<true>(w, cavg, cur, false, k0, flip_k);
 			k0 = flip_k + 1;
 		}
-		if (i == nchunks - 1) {  // last sample of the window in this submit
-			if (closed) {        // timeout_cnt reached 0, whb.cpp:691-702
+		if (i == nch - 1) {  // last sample of the window in this submit
+			if (closed) {    // timeout_cnt reached 0, whb.cpp:691-702
 				if (d.synced) {
 					for (int q = 0; q < 16; q++)
 						store_bit<2>(d, 0);
@@ -856,39 +857,10 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 				step0 += n;
 			}
 		}
-	};
-	bool hA = advance(), hB;
-	if (hA)
-		load(dvA, slot0 + i);
-	while (hA) {
-		// peek the next slot for the prefetch without disturbing the current position
-		const int sj = j, si = i, snc = nchunks, sog = og, sn = n, ss0 = slot0, scl = closed;
-		const double srd = rssi_d;
-		const long long sst = step0, slp = last_peak;
-		hB = advance();
-		const int nslot = slot0 + i;
-		j = sj; i = si; nchunks = snc; og = sog; n = sn; slot0 = ss0; closed = scl;
-		rssi_d = srd; step0 = sst; last_peak = slp;
-		if (hB)
-			load(dvB, nslot);
-		process(dvA);
-		if (!hB)
-			break;
-		advance();
-		{
-			const int sj2 = j, si2 = i, snc2 = nchunks, sog2 = og, sn2 = n, ss02 = slot0, scl2 = closed;
-			const double srd2 = rssi_d;
-			const long long sst2 = step0, slp2 = last_peak;
-			hA = advance();
-			const int nslot2 = slot0 + i;
-			j = sj2; i = si2; nchunks = snc2; og = sog2; n = sn2; slot0 = ss02; closed = scl2;
-			rssi_d = srd2; step0 = sst2; last_peak = slp2;
-			if (hA)
-				load(dvA, nslot2);
-		}
-		process(dvB);
-		if (hA)
-			advance();
+#pragma unroll
+		for (int q = 0; q < 32; q++)
+			cur[q] = nxt[q];
+		i++;
 	}
 	{
 		const uint32_t lw = drow[M - 1];

@@ -1,0 +1,126 @@
+// tfrec_amd/host/gpu_engine.cpp -- see gpu_engine.h.
+#include "gpu_engine.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+gpu_engine::gpu_engine(const std::vector<std::string> &dumpfiles, int _types, int _thresh, int _filter, int _dbg,
+		       int _device, int blocks_per_submit)
+	: files(dumpfiles), types(_types), thresh(_thresh), filter(_filter), dbg(_dbg), device(_device),
+	  bps(blocks_per_submit), n_telegrams(0)
+{
+	// one set of protocol handlers per stream, registered like main.cpp:173-218
+	for (size_t s = 0; s < files.size(); s++) {
+		std::vector<decoder *> d(TFREC_AMD_NSLOTS, (decoder *)NULL);
+		if (types & (1 << TFA_1)) d[TFREC_AMD_SLOT_TFA1] = new tfa1_decoder(TFA_1);
+		if (types & (1 << TFA_2)) d[TFREC_AMD_SLOT_TFA2] = new tfa2_decoder(TFA_2);
+		if (types & (1 << TFA_3)) d[TFREC_AMD_SLOT_TFA3] = new tfa2_decoder(TFA_3);
+		if (types & (1 << TX22)) d[TFREC_AMD_SLOT_TX22] = new tfa2_decoder(TX22);
+		if (types & (1 << TFA_WHB)) d[TFREC_AMD_SLOT_WHB] = new whb_decoder(TFA_WHB);
+		for (size_t k = 0; k < d.size(); k++)
+			if (d[k])
+				d[k]->set_params(NULL, 0, dbg);
+		decs.push_back(d);
+	}
+}
+
+gpu_engine::~gpu_engine()
+{
+	for (size_t s = 0; s < decs.size(); s++)
+		for (size_t k = 0; k < decs[s].size(); k++)
+			delete decs[s][k];
+}
+
+// The adapter contract: bring the decoder's rdata[0..64) to the state the GPU decoder had,
+// set byte_cnt, then let the unchanged handler do CRC, parsing, printing, store_data.
+void gpu_engine::replay(const tfrec_amd_event &ev)
+{
+	decoder *dec = decs[ev.stream][ev.slot];
+	if (!dec)
+		return;
+	uint8_t buf[256];
+	memset(buf, 0, sizeof(buf));
+	memcpy(buf, ev.rdata, 64);
+	dec->store_bytes(buf, 64);
+	int len = ev.byte_cnt > 256 ? 256 : ev.byte_cnt;
+	dec->store_bytes(buf, len);
+	int before = dec->count();
+	dec->flush(tfrec_amd_rssi_db(ev.slot, ev.rssi_raw), ev.offset);
+	if (ev.status == 1)
+		n_telegrams++;
+	(void)before;
+}
+
+int gpu_engine::run()
+{
+	const size_t n = files.size();
+	std::vector<FILE *> fd(n, (FILE *)NULL);
+	size_t max_blocks = 0;
+	stream_samples.assign(n, 0);
+	for (size_t s = 0; s < n; s++) {
+		fd[s] = fopen(files[s].c_str(), "rb");
+		if (!fd[s]) {
+			perror(files[s].c_str());
+			return TFREC_AMD_E_INVAL;
+		}
+		fseek(fd[s], 0, SEEK_END);
+		const size_t blocks = (size_t)ftell(fd[s]) / TFREC_AMD_BLOCK_BYTES;  // trailing partial block dropped, engine.cpp:72-76
+		fseek(fd[s], 0, SEEK_SET);
+		stream_samples[s] = (long long)blocks * TFREC_AMD_BLOCK_DEC;
+		max_blocks = std::max(max_blocks, blocks);
+	}
+	tfrec_amd_config cfg;
+	memset(&cfg, 0, sizeof(cfg));
+	cfg.n_streams = (int32_t)n;
+	cfg.types_mask = types;
+	cfg.thresh = thresh;
+	cfg.filter_type = filter;
+	cfg.device = device;
+	cfg.max_blocks = bps;
+	cfg.max_events = (int32_t)std::max<size_t>(4096, n * (size_t)bps * 64);
+	cfg.flags = 0;
+	tfrec_amd_ctx *ctx = NULL;
+	int rc = tfrec_amd_create(&cfg, &ctx);
+	if (rc) {
+		fprintf(stderr, "tfrec_amd_create: %s (%s)\n", tfrec_amd_strerror(rc), tfrec_amd_last_error());
+		return rc;
+	}
+	const size_t row = (size_t)bps * TFREC_AMD_BLOCK_BYTES;
+	std::vector<uint8_t> host(n * row);
+	std::vector<tfrec_amd_event> ev(cfg.max_events);
+	for (size_t b0 = 0; b0 < max_blocks && rc == 0; b0 += bps) {
+		const int nb = (int)std::min<size_t>(bps, max_blocks - b0);
+		for (size_t s = 0; s < n; s++) {
+			uint8_t *dst = &host[s * row];
+			const size_t want = (size_t)nb * TFREC_AMD_BLOCK_BYTES;
+			size_t got = fread(dst, 1, want, fd[s]);
+			got -= got % TFREC_AMD_BLOCK_BYTES;
+			memset(dst + got, 0x80, want - got);  // a shorter file is padded with silence (its events are cut below)
+		}
+		rc = tfrec_amd_submit_host(ctx, host.data(), row, nb);
+		if (rc)
+			break;
+		int nev = 0;
+		rc = tfrec_amd_drain_events(ctx, ev.data(), (int)ev.size(), &nev);
+		if (rc)
+			break;
+		// per stream in time order, slots in registration order like the reference's dispatch loop (fm_demod.cpp:48-49)
+		std::sort(ev.begin(), ev.begin() + nev, [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
+			if (a.stream != b.stream) return a.stream < b.stream;
+			if (a.end_sample != b.end_sample) return a.end_sample < b.end_sample;
+			return a.slot < b.slot;
+		});
+		for (int k = 0; k < nev; k++)
+			if (ev[k].end_sample < stream_samples[ev[k].stream])
+				replay(ev[k]);
+	}
+	if (rc)
+		fprintf(stderr, "tfrec_amd: %s (%s)\n", tfrec_amd_strerror(rc), tfrec_amd_last_error());
+	tfrec_amd_destroy(ctx);
+	for (size_t s = 0; s < n; s++)
+		fclose(fd[s]);
+	return rc;
+}

@@ -1,0 +1,90 @@
+// tfrec_amd/host/main.cpp -- tfrec_gpu: the reference's file-replay CLI on the GPU path.
+//
+//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d device] [-b blocks] -L dump.iq [-L more.iq ...]
+//   tfrec_gpu [-T hexmask] -X telegrams.txt
+//
+// Flags keep the reference's meaning (main.cpp:63-88, 107-164): -T sensor type bit mask (hex), -t trigger
+// threshold (fixed; 0/auto is not offered on the GPU path yet), -W wide filter, -q quiet, -D debug,
+// -L raw 8-bit IQ dump as written by "tfrec -S", -X hex telegrams for the byte-level test entry
+// (main.cpp:24-53).  Several -L files are processed as one batch, one stream each.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "gpu_engine.h"
+
+static int replay_hex(int types, int dbg, const char *fn)
+{
+	std::vector<decoder *> decs;
+	if (types & (1 << TFA_1)) decs.push_back(new tfa1_decoder(TFA_1));
+	if (types & (1 << TFA_2)) decs.push_back(new tfa2_decoder(TFA_2));
+	if (types & (1 << TFA_3)) decs.push_back(new tfa2_decoder(TFA_3));
+	if (types & (1 << TX22)) decs.push_back(new tfa2_decoder(TX22));
+	if (types & (1 << TFA_WHB)) decs.push_back(new whb_decoder(TFA_WHB));
+	FILE *fd = fopen(fn, "r");
+	if (!fd) {
+		perror("Can't open message file");
+		return 1;
+	}
+	char line[2048];
+	while (fgets(line, sizeof(line), fd)) {
+		if (line[0] == '#')
+			continue;
+		uint8_t buf[512];
+		int len = 0;
+		for (char *tok = strtok(line, " \t\r\n"); tok && len < (int)sizeof(buf); tok = strtok(NULL, " \t\r\n"))
+			buf[len++] = (uint8_t)strtol(tok, NULL, 16);
+		for (size_t k = 0; k < decs.size(); k++) {
+			decs[k]->set_params(NULL, 0, dbg);
+			decs[k]->store_bytes(buf, len);
+			decs[k]->flush(0);
+			puts("");
+			decs[k]->flush_storage();
+		}
+	}
+	fclose(fd);
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	int types = 0x07, thresh = 500, filter = 0, dbg = 0, device = 0, blocks = 16;
+	std::vector<std::string> dumps;
+	const char *hexfile = NULL;
+	int c;
+	while ((c = getopt(argc, argv, "T:t:WqDd:b:L:X:h")) != -1) {
+		switch (c) {
+		case 'T': types = (int)strtol(optarg, NULL, 16); break;
+		case 't': thresh = atoi(optarg); break;
+		case 'W': filter = 1; break;
+		case 'q': dbg = -1; break;
+		case 'D': dbg++; break;
+		case 'd': device = atoi(optarg); break;
+		case 'b': blocks = atoi(optarg); break;
+		case 'L': dumps.push_back(optarg); break;
+		case 'X': hexfile = optarg; break;
+		default:
+			fprintf(stderr, "usage: tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d dev] [-b blocks] -L dump [-L dump ...] | -X hexfile\n");
+			return c == 'h' ? 0 : 1;
+		}
+	}
+	setvbuf(stdout, NULL, _IOFBF, 1 << 16);
+	if (hexfile)
+		return replay_hex(types, dbg, hexfile);
+	if (dumps.empty()) {
+		fprintf(stderr, "tfrec_gpu: need -L <dumpfile> or -X <hexfile>\n");
+		return 1;
+	}
+	if (thresh <= 0) {
+		fprintf(stderr, "tfrec_gpu: -t must be > 0 (the reference's auto threshold is not available on the GPU path)\n");
+		return 1;
+	}
+	gpu_engine e(dumps, types, thresh, filter, dbg, device, blocks);
+	int rc = e.run();
+	fflush(stdout);
+	return rc ? 2 : 0;
+}
