@@ -17,7 +17,8 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
-			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves);
+			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
+			   hipEvent_t ev_fork, hipEvent_t ev_join);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			 size_t mask_stride, int n_streams, int n_blocks, long long sample_base, const ChainLaunch &L,
 			 tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
@@ -63,6 +64,8 @@ struct tfrec_amd_ctx {
 	int last_blocks = 0;
 	hipStream_t last_stream = nullptr;
 	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool timed = false;
 	unsigned long long uncertain_total = 0;
 };
@@ -161,6 +164,12 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	for (auto &e : c->ev)
 		if (e)
 			(void)hipEventDestroy(e);
+	if (c->ev_fork)
+		(void)hipEventDestroy(c->ev_fork);
+	if (c->ev_join)
+		(void)hipEventDestroy(c->ev_join);
+	if (c->aux)
+		(void)hipStreamDestroy(c->aux);
 	delete c;
 	return TFREC_AMD_OK;
 }
@@ -322,6 +331,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    hipMemcpy(c->d_eb, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 	}
+	if (rc == TFREC_AMD_OK && !(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
+		if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+			rc = TFREC_AMD_E_HIP;
+	}
 	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING))
 		for (auto &e : c->ev)
 			if (hipEventCreate(&e) != hipSuccess)
@@ -359,7 +374,7 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	else
 		HIPCHK(launch_pipeline(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev, c->dec_stride,
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16, c->d_dev32,
-				       c->d_events, c->d_eb, c->cfg.flags, 768));
+				       c->d_events, c->d_eb, c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join));
 	if (timing) {
 		HIPCHK(hipEventRecord(c->ev[2], st));
 		c->timed = true;

@@ -24,9 +24,20 @@
 //   K5 commit_kernel    lane per (stream, slot): walks the windows in order: validates/repairs the tfa2
 //                       speculation, runs the decoders (store_bit / flush) over the packed bits with their
 //                       persistent state (sr, rdata), emits events, commits ChainState for the next submit.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "decoder_dev.h"
 
 namespace tfrec {
+
+static int env_int(const char *name, int dflt)
+{
+	const char *v = getenv(name);
+	const int x = v ? atoi(v) : dflt;
+	return x >= 1 && x <= 64 ? x : dflt;
+}
 
 constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
 
@@ -58,11 +69,11 @@ struct BitWriter {
 
 // ------------------------------------------------------------------------------------------------ K2
 __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *__restrict__ mask, size_t mask_stride,
-						     int n_streams, int n_blocks, ChainLaunch L, WinTables T)
+						     int n_streams, int n_blocks, ChainLaunch L, WinTables T, int lanes)
 {
 	const int a = blockIdx.y;
-	const int s = blockIdx.x * 64 + threadIdx.x;
-	if (s >= n_streams)
+	const int s = blockIdx.x * lanes + threadIdx.x;
+	if ((int)threadIdx.x >= lanes || s >= n_streams)
 		return;
 	const ChainParams &p = L.params[a];
 	const int c = a * n_streams + s;
@@ -264,6 +275,7 @@ __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const
 				ow[k >> 1] |= ((uint32_t)y & 0xffffu) << (16 * (k & 1));
 			}
 		};
+		__builtin_amdgcn_sched_barrier(0);  // bound the live range of the per-sample products to one group
 		if (nvalid >= 8 * (grp + 1)) {
 #pragma unroll
 			for (int k = 8 * grp; k < 8 * grp + 8; k++)
@@ -348,8 +360,10 @@ __device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, 
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							 int32_t *__restrict__ dev32)
+							 int32_t *__restrict__ dev32, int lanes)
 {
+	if ((int)threadIdx.x >= lanes)
+		return;
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int whb = blockIdx.y;  // a wave runs one kind of biquad window
@@ -387,7 +401,11 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
 	BiquadEnd tr = T.wend[(size_t)c * T.cap];  // window 0 ran from the true state
 	Biquad f;
+	f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
+	// flat loop over (window, chunk); the chunk after the current one (same window) is always in flight
 	int j = 0, i = 0, nchunks = 0, og = 0, n = 0, slot0 = 0;
+	K3Chunk<WHB> A, B;
+	double2 ckA = make_double2(0, 0), ckB = make_double2(0, 0);
 	while (true) {
 		if (i >= nchunks) {
 			if (j > 0 && nchunks > 0) {  // window j ended without convergence: its true end state is ours
@@ -403,24 +421,28 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 			slot0 = win_slot0(og, j);
 			i = 0;
 			f.dn1 = tr.dn1; f.dn2 = tr.dn2; f.yn = tr.yn; f.yn1 = tr.yn1;
+			k3_load<WHB>(A, in, og, prev0);
+			ckA = T.ckpt[(size_t)c * T.slots + slot0];
 		}
-		K3Chunk<WHB> A;
-		k3_load<WHB>(A, in, og + kChunk * i, prev0);
-		const double2 ck = T.ckpt[(size_t)c * T.slots + slot0 + i];
+		const int inext = i + 1 < nchunks ? i + 1 : i;
+		k3_load<WHB>(B, in, og + kChunk * inext, prev0);
+		ckB = T.ckpt[(size_t)c * T.slots + slot0 + inext];
 		uint32_t ow[WHB ? 32 : 16];
 		unsigned long long pw_unused = 0;
 		const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
 		k3_filter<WHB>(f, cf, A, nv, ow, pw_unused);
 		k3_store<WHB>(out, slot0 + i, ow);
 		// bit-for-bit state match with the speculative run?  (the two last inputs are shared once 2 samples in)
-		const bool same = __double_as_longlong(f.yn) == __double_as_longlong(ck.x) &&
-				  __double_as_longlong(f.yn1) == __double_as_longlong(ck.y) && (kChunk * i + nv) >= 2;
+		const bool same = __double_as_longlong(f.yn) == __double_as_longlong(ckA.x) &&
+				  __double_as_longlong(f.yn1) == __double_as_longlong(ckA.y) && (kChunk * i + nv) >= 2;
 		if (same) {
 			tr = T.wend[(size_t)c * T.cap + j];  // the rest of the speculative run is exact
 			nchunks = 0;                         // -> next window, without the "not converged" path
 			i = 0;
 		} else {
 			i++;
+			A = B;
+			ckA = ckB;
 		}
 	}
 	st.iir.dn1 = tr.dn1;
@@ -432,11 +454,11 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 __global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							int32_t *__restrict__ dev32)
+							int32_t *__restrict__ dev32, int lanes)
 {
 	const int a = blockIdx.y;
-	const int s = blockIdx.x * 64 + threadIdx.x;
-	if (s >= n_streams)
+	const int s = blockIdx.x * lanes + threadIdx.x;
+	if ((int)threadIdx.x >= lanes || s >= n_streams)
 		return;
 	const int M = n_blocks * kBlockDec;
 	const int kind = L.params[a].kind;
@@ -547,48 +569,92 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 
 // Run one window [g0, last] of a TFA_1 (KIND 0) or TFA_2-family (KIND 1) slicer.  `f` carries the state in and
 // out; bits go to bw.  Returns with f.cur_block = block of `last`.
+// plain-value register blocks for prefetching (arrays behind references end up in scratch)
+struct Slot8 {
+	uint4 q0, q1, q2, q3, q4, q5, q6, q7;
+};
+struct Slot4 {
+	uint4 q0, q1, q2, q3;
+};
+
+// Run one window [g0, last] of a TFA_1 (KIND 0) or TFA_2-family (KIND 1) slicer.  Each 32-sample chunk is moved
+// from registers to the lane's LDS column, the next chunk's loads are issued, then the chunk is walked from
+// LDS by a rolled loop (small code, HBM latency overlapped with the state machine).
 template <int KIND>
 __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int last, bool closed,
 					   const uint32_t *__restrict__ drow, const uint32_t *__restrict__ ldslots, int prevI,
-					   int prevQ, double spb)
+					   int prevQ, double spb, uint4 *__restrict__ my_lds)
 {
+	const int n = last - g0 + 1;
+	const int nch = (n + kChunk - 1) >> 5;
 	if (KIND == 0) {
-		int g = g0;
-		while (g <= last) {
-			const int cb = g & ~7;
-			const uint4 v0 = *reinterpret_cast<const uint4 *>(drow + cb);
-			const uint4 v1 = *reinterpret_cast<const uint4 *>(drow + cb + 4);
-			const uint32_t vw[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-			int pI = prevI, pQ = prevQ;
-			if (cb > 0) {
-				const uint32_t pw = drow[cb - 1];
-				pI = (int)(int16_t)(pw & 0xffff);
-				pQ = (int)pw >> 16;
-			}
+		auto load = [&](int i) -> Slot8 {
+			const u32x4_a4 *p = reinterpret_cast<const u32x4_a4 *>(drow + g0 + kChunk * i);
+			Slot8 r;
+			u32x4_a4 v;
+			v = p[0]; r.q0 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[1]; r.q1 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[2]; r.q2 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[3]; r.q3 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[4]; r.q4 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[5]; r.q5 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[6]; r.q6 = make_uint4(v.x, v.y, v.z, v.w);
+			v = p[7]; r.q7 = make_uint4(v.x, v.y, v.z, v.w);
+			return r;
+		};
+		int pI = prevI, pQ = prevQ;
+		if (g0 > 0) {
+			const uint32_t pw = drow[g0 - 1];
+			pI = (int)(int16_t)(pw & 0xffff);
+			pQ = (int)pw >> 16;
+		}
+		Slot8 cur = load(0);
+		for (int i = 0; i < nch; i++) {
+			my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
+			my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
+			const Slot8 nxt = load(i + 1 < nch ? i + 1 : i);
+			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+#pragma unroll 1
+			for (int q = 0; 4 * q < nv; q++) {
+				const uint4 v = my_lds[q * 64];
+				const uint32_t vw[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
-				const int gk = cb + k;
-				const int I = (int)(int16_t)(vw[k] & 0xffff), Q = (int)vw[k] >> 16;
-				if (gk >= g && gk <= last)
-					tfa1_sample(f, bw, gk, I, Q, pI, pQ);
-				pI = I;
-				pQ = Q;
+				for (int t = 0; t < 4; t++) {
+					const int I = (int)(int16_t)(vw[t] & 0xffff), Q = (int)vw[t] >> 16;
+					if (4 * q + t < nv)
+						tfa1_sample(f, bw, g0 + kChunk * i + 4 * q + t, I, Q, pI, pQ);
+					pI = I;
+					pQ = Q;
+				}
 			}
-			g = cb + 8;
+			cur = nxt;
 		}
 	} else {
 		// ld = biquad output, window-relative slots of 32 samples (K3)
-		const int n = last - g0 + 1;
-		for (int r0 = 0; r0 < n; r0 += 8) {
-			const uint4 v = *reinterpret_cast<const uint4 *>(ldslots + (r0 >> 1));
-			const uint32_t vw[4] = { v.x, v.y, v.z, v.w };
+		auto load = [&](int i) -> Slot4 {
+			const uint4 *p = reinterpret_cast<const uint4 *>(ldslots + (size_t)i * 16);
+			Slot4 r;
+			r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2]; r.q3 = p[3];
+			return r;
+		};
+		Slot4 cur = load(0);
+		for (int i = 0; i < nch; i++) {
+			my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
+			const Slot4 nxt = load(i + 1 < nch ? i + 1 : i);
+			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+#pragma unroll 1
+			for (int q = 0; 8 * q < nv; q++) {
+				const uint4 v = my_lds[q * 64];
+				const uint32_t vw[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-			for (int k = 0; k < 8; k++) {
-				if (r0 + k < n) {
-					const int ld = (int)(int16_t)((vw[k >> 1] >> (16 * (k & 1))) & 0xffff);
-					tfa2_sample(f, bw, g0 + r0 + k, ld, drow, spb);
+				for (int t = 0; t < 8; t++) {
+					if (8 * q + t < nv) {
+						const int ld = (int)(int16_t)((vw[t >> 1] >> (16 * (t & 1))) & 0xffff);
+						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, drow, spb);
+					}
 				}
 			}
+			cur = nxt;
 		}
 	}
 	const int bl = last >> 13;
@@ -597,14 +663,14 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 		f.cur_block = bl;
 	}
 	if (closed && KIND == 1)  // tfa2.cpp:430-431: trailing bits before the flush
-		for (int n = 0; n < 16; n++)
+		for (int q = 0; q < 16; q++)
 			bw.put(f.last_bit);
 }
 
 template <int KIND>
 __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					    size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
-					    const WinTables &T, bool exact_lbi, int lbi_in_override)
+					    const WinTables &T, bool exact_lbi, int lbi_in_override, uint4 *__restrict__ my_lds)
 {
 	const int a = c / n_streams, s = c - a * n_streams;
 	const ChainParams &p = L.params[a];
@@ -640,7 +706,7 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
 							(size_t)win_slot0(og, j) * 16
 					      : nullptr;
-	run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb);
+	run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, my_lds);
 	bw.finish();
 	WinResult &r = T.result[(size_t)c * T.cap + j];
 	r.nbits = bw.n;
@@ -661,8 +727,12 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 // 1 TFA_2 family), each with its own pair of queues, so a wave runs one slicer type.
 __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks, ChainLaunch L,
-						    WinTables T)
+						    WinTables T, int lanes)
 {
+	__shared__ uint4 slot_lds[8 * 64];
+	uint4 *my_lds = slot_lds + threadIdx.x;
+	if ((int)threadIdx.x >= lanes)
+		return;
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int kind = blockIdx.y;
@@ -675,9 +745,9 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 			const uint2 it = T.items[(size_t)q * total + idx];
 			const int c = (int)it.x, j = (int)it.y;
 			if (kind == 0)
-				window_task<0>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0);
+				window_task<0>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds);
 			else
-				window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0);
+				window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds);
 		}
 	}
 }
@@ -697,30 +767,45 @@ struct WhbFast {
 
 // One pass over samples [k0, k1] of a slot.  PRED = false: the whole slot (no per-sample tests).
 // |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09, so (int) never saturates.
-template <bool PRED>
-__device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg, const uint32_t (&dv)[32], bool synced,
+// One pass over samples [k0, k1] of the lane's slot held in LDS (16-byte piece q of lane L at (q*64+L)*16):
+// a rolled loop of 8 groups x 4 samples keeps code and register footprint small (a fully unrolled pass lets
+// the scheduler hoist 32 samples of independent products and spill).
+__device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg, const uint4 *__restrict__ slot_lds, bool synced,
 					     int k0, int k1)
 {
-	int avg[32];
-	if (!synced) {
-#pragma unroll
-		for (int k = 0; k < 32; k++) {
-			if (!PRED || (k >= k0 && k <= k1))
-				w.avg_of = (int)iir_step(w.iir_avg, cavg, 0.5 * (double)(int)dv[k]);  // whb.cpp:653-654
-			avg[k] = w.avg_of;
-		}
-	} else {
-#pragma unroll
-		for (int k = 0; k < 32; k++)
-			avg[k] = w.avg_of;
-	}
 	uint32_t mask = 0;
+#pragma unroll 1
+	for (int q = k0 >> 2; q <= (k1 >> 2); q++) {
+		const uint4 v = slot_lds[q * 64];
+		const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
+		const bool whole = (4 * q >= k0) && (4 * q + 3 <= k1);
+		if (whole && !synced) {
 #pragma unroll
-	for (int k = 0; k < 32; k++) {
-		if (!PRED || (k >= k0 && k <= k1)) {
-			const int dev = (int)dv[k];
-			mask |= (uint32_t)(dev < avg[k] && dev > w.last_dev) << k;  // whb.cpp:662-663
-			w.last_dev = dev;
+			for (int t = 0; t < 4; t++) {
+				const int dev = (int)dv[t];
+				w.avg_of = (int)iir_step(w.iir_avg, cavg, 0.5 * (double)dev);  // whb.cpp:653-654
+				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << (4 * q + t);  // whb.cpp:662-663
+				w.last_dev = dev;
+			}
+		} else if (whole) {
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int dev = (int)dv[t];
+				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << (4 * q + t);
+				w.last_dev = dev;
+			}
+		} else {
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int k = 4 * q + t;
+				if (k >= k0 && k <= k1) {
+					const int dev = (int)dv[t];
+					if (!synced)
+						w.avg_of = (int)iir_step(w.iir_avg, cavg, 0.5 * (double)dev);
+					mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << k;
+					w.last_dev = dev;
+				}
+			}
 		}
 	}
 	return mask;
@@ -729,10 +814,10 @@ __device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg,
 __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						 const int32_t *__restrict__ dev32, int n_streams, int n_blocks, long long sample_base,
 						 ChainLaunch L, int a, WinTables T, tfrec_amd_event *__restrict__ events,
-						 EventBuf *__restrict__ eb, uint32_t flags)
+						 EventBuf *__restrict__ eb, uint32_t flags, int lanes, int ablate)
 {
-	const int s = blockIdx.x * 64 + threadIdx.x;
-	if (s >= n_streams)
+	const int s = blockIdx.x * lanes + threadIdx.x;
+	if ((int)threadIdx.x >= lanes || s >= n_streams)
 		return;
 	const ChainParams &p = L.params[a];
 	ChainState &st = L.states[a][s];
@@ -767,100 +852,114 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		}
 		return v;
 	};
-	auto load = [&](uint32_t (&dv)[32], int slot) {
+	__shared__ uint4 slot_lds[8 * 64];
+	uint4 *my_lds = slot_lds + threadIdx.x;
+	auto load_slot = [&](int slot) -> Slot8 {
 		const uint4 *pv = reinterpret_cast<const uint4 *>(dvrow + (size_t)slot * 32);
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const uint4 v = pv[q];
-			dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
-		}
+		Slot8 r;
+		r.q0 = pv[0]; r.q1 = pv[1]; r.q2 = pv[2]; r.q3 = pv[3];
+		r.q4 = pv[4]; r.q5 = pv[5]; r.q6 = pv[6]; r.q7 = pv[7];
+		return r;
 	};
-
-	int j = -1, i = 0, nch = 0, og = 0, n = 0, slot0 = 0, closed = 0;
-	uint32_t cur[32], nxt[32];
-	while (true) {
-		if (i >= nch) {  // next window (21 per second of signal: its first slot is not prefetched)
-			if (++j >= count)
-				break;
-			og = T.open[(size_t)c * T.cap + j];
-			const int close = T.close[(size_t)c * T.cap + j];
-			closed = close < M;
-			n = (closed ? close : M - 1) - og + 1;
-			nch = (n + kChunk - 1) >> 5;
-			slot0 = win_slot0(og, j);
-			i = 0;
-			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
+	struct Win {
+		int og, n, nch, slot0, closed;
+	};
+	auto read_win = [&](int jj) -> Win {
+		Win r;
+		const int jc = jj < count ? jj : count - 1;
+		r.og = T.open[(size_t)c * T.cap + jc];
+		const int close = T.close[(size_t)c * T.cap + jc];
+		r.closed = close < M;
+		r.n = (r.closed ? close : M - 1) - r.og + 1;
+		r.nch = (r.n + kChunk - 1) >> 5;
+		r.slot0 = win_slot0(r.og, jc);
+		return r;
+	};
+	if (count > 0) {
+		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
+		Slot8 cur = load_slot(cw.slot0);
+		int j = 0, i = 0;
+		while (j < count) {
+			my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
+			my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
+			// the slot after this one (same window, else first slot of the next window): in flight during processing
+			const int ns = (i + 1 < cw.nch) ? cw.slot0 + i + 1 : (j + 1 < count ? nw.slot0 : cw.slot0 + i);
+			const Slot8 nxt = load_slot(ns);
+			const int og = cw.og, n = cw.n, slot0 = cw.slot0;
+			if (i == 0 && !(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
 				step0 = 0;
 				last_peak = 0;
 			}
-			load(cur, slot0);
-		}
-		if (i + 1 < nch)
-			load(nxt, slot0 + i + 1);  // in flight while this slot is processed
-		const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
-		const long long base_step = step0 + (long long)kChunk * i;
-		int k0 = 0;
-		while (true) {
-			const WhbFast snap = w;
-			const bool was_synced = d.synced != 0;
-			uint32_t mask = (k0 == 0 && nv == kChunk) ? whb_pass<false>(w, cavg, cur, was_synced, 0, 31)
-								  : whb_pass<true>(w, cavg, cur, was_synced, k0, nv - 1);
-			int flip_k = -1;
-			while (mask) {
-				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
-				if (kmin > 31)
+			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+			const long long base_step = step0 + (long long)kChunk * i;
+			int k0 = 0;
+			while (true) {
+				const WhbFast snap = w;
+				const bool was_synced = d.synced != 0;
+				uint32_t mask = whb_pass(w, cavg, my_lds, (ablate & 2) ? true : was_synced, k0, nv - 1);
+				if (ablate & 1)
+					mask = 0;
+				int flip_k = -1;
+				while (mask) {
+					const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
+					if (kmin > 31)
+						break;
+					if (kmin > 0)
+						mask &= ~0u << (int)kmin;
+					if (!mask)
+						break;
+					const int k = __builtin_ctz(mask);
+					mask &= mask - 1;
+					const int tdiff = (int)(base_step + k - last_peak);
+					store_bit<2>(d, 0);  // whb.cpp:666-673
+					const int bit0 = d2i((tdiff + spb / 2) / spb);
+					for (int q = 1; q < bit0; q++)
+						store_bit<2>(d, 1);
+					last_peak = base_step + k;
+					if (!was_synced && d.synced) {  // the decoder locked at sample k: rssi counts from k on (:677)
+						rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);
+						if (k < nv - 1)
+							flip_k = k;
+						break;
+					}
+				}
+				if (flip_k < 0)
 					break;
-				if (kmin > 0)
-					mask &= ~0u << (int)kmin;
-				if (!mask)
-					break;
-				const int k = __builtin_ctz(mask);
-				mask &= mask - 1;
-				const int tdiff = (int)(base_step + k - last_peak);
-				store_bit<2>(d, 0);  // whb.cpp:666-673
-				const int bit0 = d2i((tdiff + spb / 2) / spb);
-				for (int q = 1; q < bit0; q++)
-					store_bit<2>(d, 1);
-				last_peak = base_step + k;
-				if (!was_synced && d.synced) {  // the decoder locked at sample k: rssi counts from k on (:677)
-					rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);
-					if (k < nv - 1)
-						flip_k = k;
-					break;
+				// rewind to the state at k0, redo [k0, flip_k] unsynced to get the state after flip_k, then go on
+				// with (flip_k, nv) in synced mode
+				w = snap;
+				(void)whb_pass(w, cavg, my_lds, false, k0, flip_k);
+				k0 = flip_k + 1;
+			}
+			if (i == cw.nch - 1) {  // last sample of the window in this submit
+				if (cw.closed) {    // timeout_cnt reached 0, whb.cpp:691-702
+					if (d.synced) {
+						for (int q = 0; q < 16; q++)
+							store_bit<2>(d, 0);
+						const unsigned long long tot = pwrow[slot0 + i];
+						flush<2>(e, d, (long long)(rssi_d + (double)(tot - rssi_base)), 0, og + n - 1);
+					}
+					rssi_d = 0;
+					rssi_base = 0;
+					step0 = 0;
+					last_peak = 0;
+				} else {  // window continues in the next submit
+					if (d.synced)
+						rssi_d += (double)(pwrow[slot0 + i] - rssi_base);
+					rssi_base = 0;
+					step0 += n;
 				}
 			}
-			if (flip_k < 0)
-				break;
-			// rewind to the state at k0, redo [k0, flip_k] unsynced to get the state after flip_k, then go on
-			// with (flip_k, nv) in synced mode
-			w = snap;
-			(void)whb_pass<true>(w, cavg, cur, false, k0, flip_k);
-			k0 = flip_k + 1;
-		}
-		if (i == nch - 1) {  // last sample of the window in this submit
-			if (closed) {    // timeout_cnt reached 0, whb.cpp:691-702
-				if (d.synced) {
-					for (int q = 0; q < 16; q++)
-						store_bit<2>(d, 0);
-					const unsigned long long tot = pwrow[slot0 + i];
-					flush<2>(e, d, (long long)(rssi_d + (double)(tot - rssi_base)), 0, og + n - 1);
-				}
-				rssi_d = 0;
-				rssi_base = 0;
-				step0 = 0;
-				last_peak = 0;
-			} else {  // window continues in the next submit
-				if (d.synced)
-					rssi_d += (double)(pwrow[slot0 + i] - rssi_base);
-				rssi_base = 0;
-				step0 += n;
+			cur = nxt;
+			if (++i >= cw.nch) {
+				j++;
+				i = 0;
+				cw = nw;
+				nw = nnw;
+				nnw = read_win(j + 2);  // needed two windows from now: its latency is hidden
 			}
 		}
-#pragma unroll
-		for (int q = 0; q < 32; q++)
-			cur[q] = nxt[q];
-		i++;
 	}
 	{
 		const uint32_t lw = drow[M - 1];
@@ -891,7 +990,8 @@ template <int KIND>
 __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_blocks, long long sample_base,
 					    const uint32_t *__restrict__ dec, size_t dec_stride,
 					    const int16_t *__restrict__ ld16, const ChainLaunch &L, const WinTables &T,
-					    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
+					    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
+					    uint4 *__restrict__ my_lds)
 {
 	const int M = n_blocks * kBlockDec;
 	const ChainParams &p = L.params[a];
@@ -904,46 +1004,62 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 	int lbi = st.last_bit_idx;  // true last_bit_idx, relative to lbi_block
 	int lbi_block = -1;
 	const WinResult *last_r = nullptr;
-	for (int j = 0; j < count; j++) {
-		const int og = T.open[(size_t)c * T.cap + j];
-		const int close = T.close[(size_t)c * T.cap + j];
-		const int last = close < M ? close : M - 1;
-		WinResult *r = &T.result[(size_t)c * T.cap + j];
-		if (KIND == 1) {
-			if (j > 0) {
-				// window j was sliced assuming last_bit_idx far in the past (kSpecLbi); check with the true value
-				if (r->first_cand_g >= 0) {
-					const int bc = r->first_cand_g >> 13;
-					const int index_c = 2 * (r->first_cand_g & (kBlockDec - 1));
-					const int lbi_c = rebase_lbi(lbi, lbi_block, bc);
-					const int tdiff = index_c - lbi_c;
-					// the speculative run saw: glitch test passed, edge counted, nothing emitted, last_bit kept
-					// (tfa2.cpp:391-409 with a huge tdiff).  The true run does the same iff:
-					const bool same = (index_c > lbi_c + 8) && !(tdiff > p.spb / 4 && tdiff < 32 * p.spb);
-					if (!same)
-						window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
-							       rebase_lbi(lbi, lbi_block, og >> 13));
-					lbi = r->lbi_out;
-				} else {
-					lbi = rebase_lbi(lbi, lbi_block, last >> 13);  // no candidate edge: it just ages
-				}
-			} else {
-				lbi = r->lbi_out;  // window 0 always runs with the exact carried value
+	// flat loop: one 32-bit word of one window's bits per iteration (lanes are at different windows)
+	int j = -1, n = 0, nbits = 0, last = 0;
+	const uint32_t *bits = nullptr;
+	const WinResult *r = nullptr;
+	uint32_t wnext = 0;
+	while (true) {
+		if (n >= nbits) {
+			if (j >= 0) {  // the window's bits are consumed: decoder::flush if its timeout fired
+				if (r->closed)
+					flush<KIND>(e, d, r->rssi_i, KIND == 1 ? r->offset : 0, last);
+				last_r = r;
 			}
-			lbi_block = last >> 13;
+			if (++j >= count)
+				break;
+			const int og = T.open[(size_t)c * T.cap + j];
+			const int close = T.close[(size_t)c * T.cap + j];
+			last = close < M ? close : M - 1;
+			WinResult *rr = &T.result[(size_t)c * T.cap + j];
+			if (KIND == 1) {
+				if (j > 0) {
+					// window j was sliced assuming last_bit_idx far in the past (kSpecLbi); check with the true value
+					if (rr->first_cand_g >= 0) {
+						const int bc = rr->first_cand_g >> 13;
+						const int index_c = 2 * (rr->first_cand_g & (kBlockDec - 1));
+						const int lbi_c = rebase_lbi(lbi, lbi_block, bc);
+						const int tdiff = index_c - lbi_c;
+						// the speculative run saw: glitch test passed, edge counted, nothing emitted, last_bit kept
+						// (tfa2.cpp:391-409 with a huge tdiff).  The true run does the same iff:
+						const bool same = (index_c > lbi_c + 8) && !(tdiff > p.spb / 4 && tdiff < 32 * p.spb);
+						if (!same)
+							window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
+								       rebase_lbi(lbi, lbi_block, og >> 13), my_lds);
+						lbi = rr->lbi_out;
+					} else {
+						lbi = rebase_lbi(lbi, lbi_block, last >> 13);  // no candidate edge: it just ages
+					}
+				} else {
+					lbi = rr->lbi_out;  // window 0 always runs with the exact carried value
+				}
+				lbi_block = last >> 13;
+			}
+			r = rr;
+			bits = T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j;
+			nbits = r->nbits;
+			n = 0;
+			if (nbits > 0)
+				wnext = bits[0];
+			continue;
 		}
-		// decoder over the window's bits (decoder::store_bit), then decoder::flush if the window closed
-		const uint32_t *bits = T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j;
-		const int nbits = r->nbits;
-		uint32_t wbits = 0;
-		for (int n = 0; n < nbits; n++) {
-			if ((n & 31) == 0)
-				wbits = bits[n >> 5];
-			store_bit<KIND>(d, (wbits >> (n & 31)) & 1);
-		}
-		if (r->closed)
-			flush<KIND>(e, d, r->rssi_i, KIND == 1 ? r->offset : 0, last);
-		last_r = r;
+		const uint32_t wbits = wnext;
+		if (n + 32 < nbits)
+			wnext = bits[(n >> 5) + 1];  // next word in flight while this one is decoded
+		const int cnt = nbits - n < 32 ? nbits - n : 32;
+		for (int q = 0; q < cnt; q++)
+			store_bit<KIND>(d, (wbits >> q) & 1);  // decoder::store_bit
+		n += cnt;
 	}
 	// ---- commit the state the next submit starts from
 	const bool open_at_end = last_r && !last_r->closed;
@@ -985,43 +1101,71 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
 						    long long sample_base, ChainLaunch L, WinTables T,
-						    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
+						    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
+						    int lanes)
 {
+	__shared__ uint4 slot_lds[8 * 64];
+	uint4 *my_lds = slot_lds + threadIdx.x;
 	const int a = blockIdx.y;
-	const int s = blockIdx.x * 64 + threadIdx.x;
-	if (s >= n_streams)
+	const int s = blockIdx.x * lanes + threadIdx.x;
+	if ((int)threadIdx.x >= lanes || s >= n_streams)
 		return;
 	const int kind = L.params[a].kind;
 	if (kind == 0)
-		commit_body<0>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags);
+		commit_body<0>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds);
 	else if (kind == 1)
-		commit_body<1>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags);
+		commit_body<1>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
 hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
-			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves)
+			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
+			   hipEvent_t ev_fork, hipEvent_t ev_join)
 {
 	if (L.n_active == 0)
 		return hipSuccess;
 	hipError_t e = hipMemsetAsync(T.queue, 0, kNQueues * sizeof(WorkQueue), st);
 	if (e != hipSuccess)
 		return e;
-	dim3 grid((n_streams + 63) / 64, L.n_active), block(64);
-	hipLaunchKernelGGL(windows_kernel, grid, block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
-	hipLaunchKernelGGL(spec_biquad_kernel, dim3(2 * slicer_waves, 2), block, 0, st, dec, dec_stride, fmdev, fmdev_stride,
-			   n_streams, n_blocks, L, T, ld16, dev32);
+	// Serial lanes are latency-bound and the chip has thousands of idle wave slots: a wave carries only a few
+	// chains (lanes_chain) / windows (lanes_win), which cuts lock-step divergence and shared stalls.
+	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 8), lanes_win = env_int("TFREC_AMD_LANES_WIN", 8),
+			 lanes_whb = env_int("TFREC_AMD_LANES_WHB", 4);
+	dim3 block(64);
+	dim3 grid((n_streams + lanes_chain - 1) / lanes_chain, L.n_active);
+	const int win_blocks = std::min(16384, (int)(((size_t)n_streams * n_blocks * 2 + lanes_win - 1) / lanes_win));
+	(void)slicer_waves;
+	hipLaunchKernelGGL(windows_kernel, grid, block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T, lanes_chain);
+	hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, fmdev, fmdev_stride,
+			   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 	hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks, L,
-			   T, ld16, dev32);
-	hipLaunchKernelGGL(slicer_kernel, dim3(slicer_waves, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T);
+			   T, ld16, dev32, lanes_chain);
+	// The WHB chain (stage 2) and the TFA chains (slicers + commit) touch disjoint state: run them side by side.
+	bool forked = false;
 	for (int a = 0; a < L.n_active; a++)
-		if (L.params[a].kind == 2)
-			hipLaunchKernelGGL(whb_kernel, dim3((n_streams + 63) / 64), block, 0, st, dec, dec_stride, dev32, n_streams,
-					   n_blocks, sample_base, L, a, T, events, eb, flags);
+		if (L.params[a].kind == 2) {
+			hipStream_t ws = st;
+			if (aux && !forked) {
+				if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess)
+					return e;
+				forked = true;
+			}
+			if (forked)
+				ws = aux;
+			hipLaunchKernelGGL(whb_kernel, dim3((n_streams + lanes_whb - 1) / lanes_whb), block, 0, ws, dec, dec_stride,
+					   dev32, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, lanes_whb,
+					   env_int("TFREC_AMD_ABLATE", 64) & 63);
+		}
+	if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
+		return e;
+	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
+			   lanes_win);
 	hipLaunchKernelGGL(commit_kernel, grid, block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
-			   events, eb, flags);
+			   events, eb, flags, lanes_chain);
+	if (forked && (e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess)
+		return e;
 	return hipGetLastError();
 }
 
