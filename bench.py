@@ -67,7 +67,8 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
             try:
                 out = subprocess.run([O.REF_DRIVER, "time", "%x" % types, str(thresh), "0", p, "1"],
                                      capture_output=True, text=True, check=True, timeout=600)
-                r = json.loads(out.stderr.strip().splitlines()[-1])
+                line = [ln for ln in out.stderr.splitlines() if ln.startswith('{"seconds"')][-1]
+                r = json.loads(line)
                 res = dict(value=round(r["msps"], 3), unit="MSamples/s", cores=1, kind="reference",
                            sample="%d streams x %d blocks of the bench batch concatenated, real reference hot path "
                                   "(oracle/_ref/ref_driver, g++ -O3 -ffast-math as the reference Makefile), 1 thread"
@@ -153,7 +154,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    fe_ms, ch_ms, n_events = [], [], 0
+    kt = {}
+    n_events = 0
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -161,9 +163,9 @@ def main():
     for _ in range(a.steps):
         ev = step()
         n_events += len(ev)
-        t = r.timings()  # HIP events recorded on the stream the kernels were launched on
-        fe_ms.append(t["frontend_ms"])
-        ch_ms.append(t["chains_ms"])
+        t = r.timings()  # HIP events recorded on the streams the kernels were launched on
+        for k, v in t.items():
+            kt.setdefault(k, []).append(v)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -178,11 +180,20 @@ def main():
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
-        fe = float(np.mean(fe_ms)) if fe_ms else 0.0
-        ch = float(np.mean(ch_ms)) if ch_ms else 0.0
-        dom_name, dom_ms = ("chains_kernel", ch) if ch >= fe else ("frontend_kernel", fe)
+        kms = {k[:-3] + "_kernel": float(np.mean(v)) for k, v in kt.items() if k not in ("chains_ms", "total_ms")}
+        dom_name = max(kms, key=kms.get)
+        dom_ms = kms[dom_name]
         alg_bytes = 2.0 * samples_per_step_gpu  # 2 B per complex input sample, one launch = one batch
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_traffic.json, collected and corrected as
+        # MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if (tj.get("streams"), tj.get("blocks"), tj.get("types")) == (n_streams, n_blocks, a.types):
+                traffic = tj["kernels"].get(dom_name, {}).get("hbm_bytes")
+        except Exception:
+            pass
         out = {
             "metric": "IQ MSamples/s through demod+decode (batched streams)",
             "value": round(value, 3),
@@ -195,8 +206,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int32+f64",
-            "data": "synthetic (tfrec_amd.synth, SURVEY App. C recipe; %d distinct streams per GPU tiled over %d)" % (
-                unique, n_streams),
+            "data": "synthetic (tfrec_amd.synth, SURVEY App. C recipe; %d distinct streams per GPU%s)" % (
+                unique, "" if unique == n_streams else " tiled over %d" % n_streams),
             "config": {
                 "workload": "configs[2]: %d batched 1.536 MS/s streams x %d blocks x protocols mask 0x%x, -t %d, per GPU"
                             % (n_streams, n_blocks, a.types, a.thresh),
@@ -207,9 +218,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernels_ms": {"frontend_kernel": round(fe, 4), "chains_kernel": round(ch, 4)},
-                "frontend_achieved_GBs": round(alg_bytes / (fe * 1e-3) / 1e9, 2) if fe > 0 else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items())},
+                "gpu_ms_per_step": round(float(np.mean(kt.get("total_ms", [0.0]))), 4),
             },
         }
         if a.cpu_budget > 0 and world == 1:

@@ -86,9 +86,11 @@ typedef struct tfrec_amd_ctx tfrec_amd_ctx;
 
 /* kernel timings of the last submit (TFREC_AMD_F_TIMING), milliseconds */
 typedef struct {
-	float frontend_ms; /* u8->s16 + 2-stage decimating FIR + trigger mask kernel */
-	float chains_ms;   /* demodulator/decoder chain kernel(s) */
+	float frontend_ms; /* u8->s16 + 2-stage decimating FIR + trigger mask + FM discriminator kernel */
+	float chains_ms;   /* all demodulator/decoder kernels together (end of front end -> end of last kernel) */
 	float total_ms;    /* first kernel start to last kernel end */
+	/* individual kernels of the window-parallel pipeline (0 when not run); whb_ms runs beside slicer+commit */
+	float windows_ms, spec_biquad_ms, fix_biquad_ms, slicer_ms, commit_ms, whb_ms;
 } tfrec_amd_timings;
 
 const char *tfrec_amd_version(void);

@@ -45,7 +45,8 @@ class Config(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("frontend_ms", C.c_float), ("chains_ms", C.c_float), ("total_ms", C.c_float)]
+    _fields_ = [(n, C.c_float) for n in ("frontend_ms", "chains_ms", "total_ms", "windows_ms", "spec_biquad_ms",
+                                         "fix_biquad_ms", "slicer_ms", "commit_ms", "whb_ms")]
 
 
 EVENT_DTYPE = np.dtype(
@@ -209,7 +210,7 @@ class Receiver:
     def timings(self) -> dict:
         t = Timings()
         _check(self.L, self.L.tfrec_amd_get_timings(self.h, C.byref(t)))
-        return dict(frontend_ms=t.frontend_ms, chains_ms=t.chains_ms, total_ms=t.total_ms)
+        return {n: float(getattr(t, n)) for n, _ in Timings._fields_}
 
 
 def event_tuples(events: np.ndarray, stream: int | None = None):

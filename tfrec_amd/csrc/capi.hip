@@ -18,7 +18,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
-			   hipEvent_t ev_fork, hipEvent_t ev_join);
+			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			 size_t mask_stride, int n_streams, int n_blocks, long long sample_base, const ChainLaunch &L,
 			 tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
@@ -66,6 +66,8 @@ struct tfrec_amd_ctx {
 	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
 	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipEvent_t tev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	bool whb_active = false;
 	bool timed = false;
 	unsigned long long uncertain_total = 0;
 };
@@ -162,6 +164,9 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_eb);
 	(void)hipFree(c->d_stage);
 	for (auto &e : c->ev)
+		if (e)
+			(void)hipEventDestroy(e);
+	for (auto &e : c->tev)
 		if (e)
 			(void)hipEventDestroy(e);
 	if (c->ev_fork)
@@ -337,10 +342,17 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 	}
-	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING))
+	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING)) {
 		for (auto &e : c->ev)
 			if (hipEventCreate(&e) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
+		if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS))
+			for (auto &e : c->tev)
+				if (hipEventCreate(&e) != hipSuccess)
+					rc = TFREC_AMD_E_HIP;
+	}
+	for (int a = 0; a < c->launch.n_active; a++)
+		c->whb_active = c->whb_active || c->launch.params[a].kind == 2;
 	if (rc != TFREC_AMD_OK) {
 		tfrec_amd_destroy(c);
 		return rc;
@@ -374,7 +386,8 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	else
 		HIPCHK(launch_pipeline(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev, c->dec_stride,
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16, c->d_dev32,
-				       c->d_events, c->d_eb, c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join));
+				       c->d_events, c->d_eb, c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
+				       (timing && c->tev[0]) ? c->tev : nullptr));
 	if (timing) {
 		HIPCHK(hipEventRecord(c->ev[2], st));
 		c->timed = true;
@@ -510,6 +523,16 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	HIPCHK(hipEventElapsedTime(&out->frontend_ms, c->ev[0], c->ev[1]));
 	HIPCHK(hipEventElapsedTime(&out->chains_ms, c->ev[1], c->ev[2]));
 	HIPCHK(hipEventElapsedTime(&out->total_ms, c->ev[0], c->ev[2]));
+	out->windows_ms = out->spec_biquad_ms = out->fix_biquad_ms = out->slicer_ms = out->commit_ms = out->whb_ms = 0;
+	if (c->tev[0]) {
+		HIPCHK(hipEventElapsedTime(&out->windows_ms, c->tev[0], c->tev[1]));
+		HIPCHK(hipEventElapsedTime(&out->spec_biquad_ms, c->tev[1], c->tev[2]));
+		HIPCHK(hipEventElapsedTime(&out->fix_biquad_ms, c->tev[2], c->tev[3]));
+		HIPCHK(hipEventElapsedTime(&out->slicer_ms, c->tev[3], c->tev[4]));
+		HIPCHK(hipEventElapsedTime(&out->commit_ms, c->tev[4], c->tev[5]));
+		if (c->whb_active)
+			HIPCHK(hipEventElapsedTime(&out->whb_ms, c->tev[6], c->tev[7]));
+	}
 	return TFREC_AMD_OK;
 }
 

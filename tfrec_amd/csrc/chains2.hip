@@ -47,96 +47,143 @@ __device__ __forceinline__ int rebase_lbi(int lbi, int from_block, int to_block)
 	return lbi ? lbi - kIndexSpan * (to_block - from_block) : 0;
 }
 
+// Packed bit output of a slicer lane.  A completed 32-bit word is parked in a register and written by
+// chunk_end(), which the caller invokes unconditionally once per 32-sample chunk (a slicer emits < 0.5 bit per
+// sample, so at most one word completes per chunk): the hot loop has no conditional global store, and the
+// prefetch waits never have to cover a store issued a moment ago.
 struct BitWriter {
 	uint32_t *base;
 	uint32_t acc;
 	int n;
+	uint32_t pend;
+	int pend_idx;  // -1: nothing parked
 	__device__ __forceinline__ void put(int bit)
 	{
 		acc |= (uint32_t)bit << (n & 31);
 		n++;
 		if ((n & 31) == 0) {
-			base[(n >> 5) - 1] = acc;
+			if (pend_idx >= 0)
+				base[pend_idx] = pend;  // second completion inside one chunk (only the 16 trailing bits can do it)
+			pend = acc;
+			pend_idx = (n >> 5) - 1;
 			acc = 0;
 		}
 	}
+	__device__ __forceinline__ void chunk_end()
+	{
+		const int idx = pend_idx >= 0 ? pend_idx : (n >> 5);
+		base[idx] = pend_idx >= 0 ? pend : acc;  // rewriting the partial word is harmless
+		pend_idx = -1;
+	}
 	__device__ __forceinline__ void finish()
 	{
+		chunk_end();
 		if (n & 31)
 			base[n >> 5] = acc;
 	}
 };
 
 // ------------------------------------------------------------------------------------------------ K2
+// One WAVE per stream: 64 mask words are loaded coalesced per step, a ballot finds the non-zero ones, and
+// a wave-uniform scalar walk over runs of non-zero words maintains, for every active slot of the stream, the
+// window state (a window opens at a trigger sample while the timeout counter is 0 and its flush fires W-1
+// samples after the last trigger: tfa1.cpp:147-149,179 / tfa2.cpp:351-355,428 / whb.cpp:636-641,691).
+// A gap that closes a window is >= W-1 >= 355 samples, so it always spans whole 64-bit words: only the first
+// trigger of a run's first word and the last trigger of its last word matter.
 __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *__restrict__ mask, size_t mask_stride,
-						     int n_streams, int n_blocks, ChainLaunch L, WinTables T, int lanes)
+						     int n_streams, int n_blocks, ChainLaunch L, WinTables T)
 {
-	const int a = blockIdx.y;
-	const int s = blockIdx.x * lanes + threadIdx.x;
-	if ((int)threadIdx.x >= lanes || s >= n_streams)
-		return;
-	const ChainParams &p = L.params[a];
-	const int c = a * n_streams + s;
-	const int W = p.window;
+	const int s = blockIdx.x;
+	const int lane = threadIdx.x;
 	const int M = n_blocks * kBlockDec;
 	const int nwords = M >> 6;
 	const unsigned long long *mrow = mask + (size_t)s * mask_stride;
-	const int t0 = L.states[a][s].timeout_cnt;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-
-	bool open = t0 > 0;
-	int open_g = 0;
-	int last_trig = open ? t0 - W : -(1 << 29);  // virtual trigger that leaves t0 samples of window
-	int count = 0;
-	bool overflow = false;
-	auto emit = [&](int og, int close) {
-		if (count < T.cap) {
-			T.open[(size_t)c * T.cap + count] = og;
-			T.close[(size_t)c * T.cap + count] = close;
-			if (p.kind < 2) {
-				const int last = close < M ? close : M - 1;
-				const int q = 2 * p.kind + ((last - og + 1) >= kLongWindow ? 0 : 1);
-				const uint32_t idx = atomicAdd(&T.queue[q].count, 1u);
-				T.items[(size_t)q * total + idx] = make_uint2((uint32_t)c, (uint32_t)count);
+	// per active slot, wave-uniform
+	int W[kNSlots], t0[kNSlots], open_g[kNSlots], last_trig[kNSlots], count[kNSlots];
+	bool open[kNSlots], overflow = false;
+#pragma unroll
+	for (int a = 0; a < kNSlots; a++) {
+		const bool act = a < L.n_active;
+		W[a] = act ? L.params[a].window : 400;
+		t0[a] = act ? L.states[a][s].timeout_cnt : 0;
+		open[a] = t0[a] > 0;
+		open_g[a] = 0;
+		last_trig[a] = open[a] ? t0[a] - W[a] : -(1 << 29);  // virtual trigger leaving t0 samples of window
+		count[a] = 0;
+	}
+	auto emit = [&](int a, int og, int close) {
+		if (lane != 0)
+			return;
+		const int c = a * n_streams + s;
+		if (count[a] < T.cap) {
+			T.open[(size_t)c * T.cap + count[a]] = og;
+			T.close[(size_t)c * T.cap + count[a]] = close;
+			const int kind = L.params[a].kind;
+			const int last = close < M ? close : M - 1;
+			const int lng = (last - og + 1) >= kLongWindow ? 0 : 1;
+			if (kind < 2) {  // slicer work item
+				const uint32_t idx = atomicAdd(&T.queue[2 * kind + lng].count, 1u);
+				T.items[(size_t)(2 * kind + lng) * total + idx] = make_uint2((uint32_t)c, (uint32_t)count[a]);
 			}
-			if (p.kind > 0) {  // the chain owns a biquad: speculative window run (K3a)
-				const int last = close < M ? close : M - 1;
-				const int q = 2 + 2 * p.kind + ((last - og + 1) >= kLongWindow ? 0 : 1);  // 4,5: TFA_2 family; 6,7: WHB
-				const uint32_t idx = atomicAdd(&T.queue[q].count, 1u);
-				T.items[(size_t)q * total + idx] = make_uint2((uint32_t)c, (uint32_t)count);
+			if (kind > 0) {  // the chain owns a biquad: speculative window run (K3a); 4,5: TFA_2 family; 6,7: WHB
+				const uint32_t idx = atomicAdd(&T.queue[2 + 2 * kind + lng].count, 1u);
+				T.items[(size_t)(2 + 2 * kind + lng) * total + idx] = make_uint2((uint32_t)c, (uint32_t)count[a]);
 			}
-			count++;
 		} else
 			overflow = true;
 	};
-	for (int w = 0; w < nwords; w++) {
-		const unsigned long long m = mrow[w];
-		if (!m)
-			continue;
-		// a gap that closes a window is >= W-1 >= 355 samples, so it always spans whole words:
-		// only the first and last trigger of a non-zero word matter
-		const int first = (w << 6) + __builtin_ctzll(m);
-		if (open && first > last_trig + W - 1) {
-			emit(open_g, last_trig + W - 1);
-			open = false;
+	for (int w0 = 0; w0 < nwords; w0 += 64) {
+		const int w = w0 + lane;
+		const unsigned long long m = w < nwords ? mrow[w] : 0ull;
+		unsigned long long nz = __ballot(m != 0);
+		const int first_bit = m ? __builtin_ctzll(m) : 0;
+		const int last_bit = m ? 63 - __builtin_clzll(m) : 0;
+		while (nz) {
+			const int l = __builtin_ctzll(nz);
+			const unsigned long long run = ~(nz >> l);  // its lowest set bit marks where the run of ones from l ends
+			const int len = run ? __builtin_ctzll(run) : 64 - l;
+			const int l2 = l + len - 1;
+			nz = (l2 >= 63) ? 0ull : (nz & (~0ull << (l2 + 1)));
+			const int first = ((w0 + l) << 6) + __builtin_amdgcn_readlane(first_bit, l);
+			const int lastt = ((w0 + l2) << 6) + __builtin_amdgcn_readlane(last_bit, l2);
+#pragma unroll
+			for (int a = 0; a < kNSlots; a++) {
+				if (a < L.n_active) {
+					if (open[a] && first > last_trig[a] + W[a] - 1) {
+						emit(a, open_g[a], last_trig[a] + W[a] - 1);
+						count[a]++;
+						open[a] = false;
+					}
+					if (!open[a]) {
+						open[a] = true;
+						open_g[a] = first;
+					}
+					last_trig[a] = lastt;
+				}
+			}
 		}
-		if (!open) {
-			open = true;
-			open_g = first;
+	}
+#pragma unroll
+	for (int a = 0; a < kNSlots; a++) {
+		if (a < L.n_active) {
+			int tnext = 0;
+			if (open[a]) {
+				const int close = last_trig[a] + W[a] - 1;
+				emit(a, open_g[a], close);
+				count[a]++;
+				if (close >= M)
+					tnext = close - (M - 1);
+			}
+			if (lane == 0) {
+				const int c = a * n_streams + s;
+				T.count[c] = count[a] < T.cap ? count[a] : T.cap;
+				T.cont[c] = t0[a] > 0 ? 1 : 0;
+				T.timeout_next[c] = tnext;
+			}
 		}
-		last_trig = (w << 6) + 63 - __builtin_clzll(m);
 	}
-	int tnext = 0;
-	if (open) {
-		const int close = last_trig + W - 1;
-		emit(open_g, close);
-		if (close >= M)
-			tnext = close - (M - 1);
-	}
-	T.count[c] = count;
-	T.cont[c] = t0 > 0 ? 1 : 0;
-	T.timeout_next[c] = tnext;
-	if (overflow)
+	if (overflow && lane == 0)
 		*T.overflow = 1;
 }
 
@@ -614,9 +661,11 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 			my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
 			const Slot8 nxt = load(i + 1 < nch ? i + 1 : i);
 			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+			uint4 vn = my_lds[0];
 #pragma unroll 1
 			for (int q = 0; 4 * q < nv; q++) {
-				const uint4 v = my_lds[q * 64];
+				const uint4 v = vn;
+				vn = my_lds[((q + 1) & 7) * 64];
 				const uint32_t vw[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 				for (int t = 0; t < 4; t++) {
@@ -627,6 +676,7 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 					pQ = Q;
 				}
 			}
+			bw.chunk_end();
 			cur = nxt;
 		}
 	} else {
@@ -642,9 +692,11 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 			my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
 			const Slot4 nxt = load(i + 1 < nch ? i + 1 : i);
 			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+			uint4 vn = my_lds[0];
 #pragma unroll 1
 			for (int q = 0; 8 * q < nv; q++) {
-				const uint4 v = my_lds[q * 64];
+				const uint4 v = vn;
+				vn = my_lds[((q + 1) & 3) * 64];
 				const uint32_t vw[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 				for (int t = 0; t < 8; t++) {
@@ -654,6 +706,7 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 					}
 				}
 			}
+			bw.chunk_end();
 			cur = nxt;
 		}
 	}
@@ -701,7 +754,7 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	} else {
 		f.lbi = kSpecLbi;  // speculation, validated by commit_kernel
 	}
-	BitWriter bw{ T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0u, 0 };
+	BitWriter bw{ T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0u, 0, 0u, -1 };
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
 							(size_t)win_slot0(og, j) * 16
@@ -774,9 +827,11 @@ __device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg,
 					     int k0, int k1)
 {
 	uint32_t mask = 0;
+	uint4 vn = slot_lds[(k0 >> 2) * 64];
 #pragma unroll 1
 	for (int q = k0 >> 2; q <= (k1 >> 2); q++) {
-		const uint4 v = slot_lds[q * 64];
+		const uint4 v = vn;
+		vn = slot_lds[((q + 1) & 7) * 64];  // next group's read is in flight while this one is processed
 		const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
 		const bool whole = (4 * q >= k0) && (4 * q + 3 <= k1);
 		if (whole && !synced) {
@@ -827,8 +882,18 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 	const uint32_t *dvrow = reinterpret_cast<const uint32_t *>(dev32 + (size_t)s * T.slots * 32);
 	const unsigned long long *pwrow = T.pw + (size_t)s * T.slots;
 	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
+	// the decoder's persistent rdata[256] lives in LDS while the kernel runs: no global stores in the hot loop
+	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
+	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
+#pragma unroll
+		for (int q = 0; q < 16; q++)
+			dst[q] = src[q];
+	}
 	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
-	       st.rdata };
+	       my_rdata };
 	WhbFast w{ st.iir_avg, st.avg_of, st.last_dev };
 	const BiquadCoef cavg = p.iir_avg;
 	const double spb = p.spb;
@@ -966,6 +1031,13 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		st.prev_i = (int)(int16_t)(lw & 0xffff);
 		st.prev_q = (int)lw >> 16;
 	}
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(st.rdata);
+#pragma unroll
+		for (int q = 0; q < 16; q++)
+			dst[q] = src[q];
+	}
 	st.timeout_cnt = T.timeout_next[c];
 	st.last_dev = w.last_dev;
 	st.avg_of = w.avg_of;
@@ -991,7 +1063,7 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 					    const uint32_t *__restrict__ dec, size_t dec_stride,
 					    const int16_t *__restrict__ ld16, const ChainLaunch &L, const WinTables &T,
 					    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
-					    uint4 *__restrict__ my_lds)
+					    uint4 *__restrict__ my_lds, uint8_t *__restrict__ my_rdata)
 {
 	const int M = n_blocks * kBlockDec;
 	const ChainParams &p = L.params[a];
@@ -999,8 +1071,15 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 	const int c = a * n_streams + s;
 	const int count = T.count[c];
 	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
+#pragma unroll
+		for (int q = 0; q < 16; q++)
+			dst[q] = src[q];
+	}
 	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
-	       st.rdata };
+	       my_rdata };
 	int lbi = st.last_bit_idx;  // true last_bit_idx, relative to lbi_block
 	int lbi_block = -1;
 	const WinResult *last_r = nullptr;
@@ -1090,6 +1169,13 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 		st.prev_i = (int)(int16_t)(lw & 0xffff);
 		st.prev_q = (int)lw >> 16;
 	}
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(st.rdata);
+#pragma unroll
+		for (int q = 0; q < 16; q++)
+			dst[q] = src[q];
+	}
 	st.sr = d.sr;
 	st.sr_cnt = d.sr_cnt;
 	st.byte_cnt = d.byte_cnt;
@@ -1105,16 +1191,20 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 						    int lanes)
 {
 	__shared__ uint4 slot_lds[8 * 64];
+	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
 	uint4 *my_lds = slot_lds + threadIdx.x;
+	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
 	const int a = blockIdx.y;
 	const int s = blockIdx.x * lanes + threadIdx.x;
 	if ((int)threadIdx.x >= lanes || s >= n_streams)
 		return;
 	const int kind = L.params[a].kind;
 	if (kind == 0)
-		commit_body<0>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds);
+		commit_body<0>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
+			       my_rdata);
 	else if (kind == 1)
-		commit_body<1>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds);
+		commit_body<1>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
+			       my_rdata);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -1122,26 +1212,36 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
-			   hipEvent_t ev_fork, hipEvent_t ev_join)
+			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev)
 {
+	// tev (optional, 9 events): 0 start, 1 after windows, 2 after spec, 3 after fix, 4 after slicer, 5 after commit,
+	// 6/7 around whb (on its own stream)
+	auto mark = [&](int k, hipStream_t s_) {
+		if (tev)
+			(void)hipEventRecord(tev[k], s_);
+	};
 	if (L.n_active == 0)
 		return hipSuccess;
 	hipError_t e = hipMemsetAsync(T.queue, 0, kNQueues * sizeof(WorkQueue), st);
 	if (e != hipSuccess)
 		return e;
-	// Serial lanes are latency-bound and the chip has thousands of idle wave slots: a wave carries only a few
-	// chains (lanes_chain) / windows (lanes_win), which cuts lock-step divergence and shared stalls.
-	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 8), lanes_win = env_int("TFREC_AMD_LANES_WIN", 8),
-			 lanes_whb = env_int("TFREC_AMD_LANES_WHB", 4);
+	// Lanes per wave for the serial kernels (tunable for experiments: TFREC_AMD_LANES_*).  Measured on MI355X:
+	// fewer lanes per wave (less lock-step divergence, more waves) is NOT faster -- full waves win.
+	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64),
+			 lanes_whb = env_int("TFREC_AMD_LANES_WHB", 64);
 	dim3 block(64);
 	dim3 grid((n_streams + lanes_chain - 1) / lanes_chain, L.n_active);
 	const int win_blocks = std::min(16384, (int)(((size_t)n_streams * n_blocks * 2 + lanes_win - 1) / lanes_win));
 	(void)slicer_waves;
-	hipLaunchKernelGGL(windows_kernel, grid, block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T, lanes_chain);
+	mark(0, st);
+	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
+	mark(1, st);
 	hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, fmdev, fmdev_stride,
 			   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
+	mark(2, st);
 	hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks, L,
 			   T, ld16, dev32, lanes_chain);
+	mark(3, st);
 	// The WHB chain (stage 2) and the TFA chains (slicers + commit) touch disjoint state: run them side by side.
 	bool forked = false;
 	for (int a = 0; a < L.n_active; a++)
@@ -1154,16 +1254,20 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			}
 			if (forked)
 				ws = aux;
+			mark(6, ws);
 			hipLaunchKernelGGL(whb_kernel, dim3((n_streams + lanes_whb - 1) / lanes_whb), block, 0, ws, dec, dec_stride,
 					   dev32, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, lanes_whb,
 					   env_int("TFREC_AMD_ABLATE", 64) & 63);
+			mark(7, ws);
 		}
 	if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
 		return e;
 	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
 			   lanes_win);
+	mark(4, st);
 	hipLaunchKernelGGL(commit_kernel, grid, block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
 			   events, eb, flags, lanes_chain);
+	mark(5, st);
 	if (forked && (e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess)
 		return e;
 	return hipGetLastError();
