@@ -302,6 +302,7 @@ __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const
 					  uint32_t (&ow)[WHB ? 32 : 16], unsigned long long &pw)
 {
 	int pI = (int)(int16_t)(ch.prevw & 0xffff), pQ = (int)ch.prevw >> 16;
+	BiquadT bt = iirt_enter(f, cf);
 #pragma unroll
 	for (int i = 0; i < (WHB ? 32 : 16); i++)
 		ow[i] = 0;
@@ -311,14 +312,14 @@ __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const
 			int y;
 			if (WHB) {
 				const int I = (int)(int16_t)(ch.w[k] & 0xffff), Q = (int)ch.w[k] >> 16;
-				y = iir_step_i(f, cf, fm_dev_nrzs(I, Q, pI, pQ));  // whb.cpp:651-652
+				y = (int)iir_step_t(f, bt, cf, (double)fm_dev_nrzs(I, Q, pI, pQ));  // whb.cpp:651-652
 				pw += (unsigned long long)(uint32_t)(I * I + Q * Q);
 				pI = I;
 				pQ = Q;
 				ow[k] = (uint32_t)y;
 			} else {
 				const int x = (int)(int16_t)((ch.w[k >> 1] >> (16 * (k & 1))) & 0xffff);
-				y = iir_step_i(f, cf, x);  // tfa2.cpp:362
+				y = (int)iir_step_t(f, bt, cf, (double)x);  // tfa2.cpp:362
 				ow[k >> 1] |= ((uint32_t)y & 0xffffu) << (16 * (k & 1));
 			}
 		};
@@ -820,36 +821,58 @@ struct WhbFast {
 
 // One pass over samples [k0, k1] of a slot.  PRED = false: the whole slot (no per-sample tests).
 // |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09, so (int) never saturates.
-// One pass over samples [k0, k1] of the lane's slot held in LDS (16-byte piece q of lane L at (q*64+L)*16):
-// a rolled loop of 8 groups x 4 samples keeps code and register footprint small (a fully unrolled pass lets
-// the scheduler hoist 32 samples of independent products and spill).
+// One pass over samples [k0, k1] of the lane's slot held in LDS (16-byte piece q of lane L at (q*64+L)*16).
+// Three separate simple loops -- whole slot unsynced (rolled, 4 samples per ds_read_b128), whole slot synced
+// (unrolled compares), partial slot (window tails, rewinds) -- so that the common loops carry no divergent
+// control flow inside and the filter state stays in fixed registers.
 __device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg, const uint4 *__restrict__ slot_lds, bool synced,
 					     int k0, int k1)
 {
 	uint32_t mask = 0;
-	uint4 vn = slot_lds[(k0 >> 2) * 64];
+	const bool full = (k0 == 0) && (k1 == kChunk - 1);
+	if (full && !synced) {
+		Biquad f = w.iir_avg;
+		BiquadT bt = iirt_enter(f, cavg);
+		int avg = w.avg_of, last = w.last_dev;
+		uint4 vn = slot_lds[0];
 #pragma unroll 1
-	for (int q = k0 >> 2; q <= (k1 >> 2); q++) {
-		const uint4 v = vn;
-		vn = slot_lds[((q + 1) & 7) * 64];  // next group's read is in flight while this one is processed
-		const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
-		const bool whole = (4 * q >= k0) && (4 * q + 3 <= k1);
-		if (whole && !synced) {
+		for (int q = 0; q < 8; q++) {
+			const uint4 v = vn;
+			vn = slot_lds[((q + 1) & 7) * 64];  // next group's read is in flight while this one is processed
+			const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
+			uint32_t m4 = 0;
 #pragma unroll
 			for (int t = 0; t < 4; t++) {
 				const int dev = (int)dv[t];
-				w.avg_of = (int)iir_step(w.iir_avg, cavg, 0.5 * (double)dev);  // whb.cpp:653-654
-				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << (4 * q + t);  // whb.cpp:662-663
-				w.last_dev = dev;
+				avg = (int)iir_step_t(f, bt, cavg, 0.5 * (double)dev);      // whb.cpp:653-654
+				m4 |= (uint32_t)(dev < avg && dev > last) << t;             // whb.cpp:662-663
+				last = dev;
 			}
-		} else if (whole) {
+			mask |= m4 << (4 * q);
+		}
+		w.iir_avg = f;
+		w.avg_of = avg;
+		w.last_dev = last;
+	} else if (full) {
+		const int avg = w.avg_of;
+		int last = w.last_dev;
+#pragma unroll
+		for (int q = 0; q < 8; q++) {
+			const uint4 v = slot_lds[q * 64];
+			const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 			for (int t = 0; t < 4; t++) {
 				const int dev = (int)dv[t];
-				mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << (4 * q + t);
-				w.last_dev = dev;
+				mask |= (uint32_t)(dev < avg && dev > last) << (4 * q + t);
+				last = dev;
 			}
-		} else {
+		}
+		w.last_dev = last;
+	} else {
+#pragma unroll 1
+		for (int q = k0 >> 2; q <= (k1 >> 2); q++) {
+			const uint4 v = slot_lds[q * 64];
+			const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 			for (int t = 0; t < 4; t++) {
 				const int k = 4 * q + t;
@@ -899,6 +922,10 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 	const double spb = p.spb;
 	const double thr = 3 * spb / 4;        // whb.cpp:664
 	const int tmin = (int)floor(thr) + 1;  // smallest integer tdiff with tdiff > thr
+	// (int)((tdiff + spb/2) / spb) is an exact shift when spb is a power of two (the reference's WHB: 64.0)
+	const int spb_i = (int)spb;
+	const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
+	const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
 	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
 	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
 	unsigned long long rssi_base = 0;      // power prefix just before the first synced sample (this submit)
@@ -945,8 +972,10 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		Slot8 cur = load_slot(cw.slot0);
 		int j = 0, i = 0;
 		while (j < count) {
-			my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
-			my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
+			if (!(ablate & 8)) {
+				my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
+				my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
+			}
 			// the slot after this one (same window, else first slot of the next window): in flight during processing
 			const int ns = (i + 1 < cw.nch) ? cw.slot0 + i + 1 : (j + 1 < count ? nw.slot0 : cw.slot0 + i);
 			const Slot8 nxt = load_slot(ns);
@@ -962,7 +991,7 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 			while (true) {
 				const WhbFast snap = w;
 				const bool was_synced = d.synced != 0;
-				uint32_t mask = whb_pass(w, cavg, my_lds, (ablate & 2) ? true : was_synced, k0, nv - 1);
+				uint32_t mask = (ablate & 4) ? (cur.q0.x & 1u) : whb_pass(w, cavg, my_lds, (ablate & 2) ? true : was_synced, k0, nv - 1);
 				if (ablate & 1)
 					mask = 0;
 				int flip_k = -1;
@@ -977,8 +1006,8 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 					const int k = __builtin_ctz(mask);
 					mask &= mask - 1;
 					const int tdiff = (int)(base_step + k - last_peak);
-					store_bit<2>(d, 0);  // whb.cpp:666-673
-					const int bit0 = d2i((tdiff + spb / 2) / spb);
+					store_bit<2>(d, 0);  // whb.cpp:666-673: one 0, then (bit0 - 1) ones
+					const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
 					for (int q = 1; q < bit0; q++)
 						store_bit<2>(d, 1);
 					last_peak = base_step + k;
