@@ -408,13 +408,13 @@ __device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, 
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							 int32_t *__restrict__ dev32, int lanes)
+							 int32_t *__restrict__ dev32, int lanes, int whb)
 {
 	if ((int)threadIdx.x >= lanes)
 		return;
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-	const int whb = blockIdx.y;  // a wave runs one kind of biquad window
+	// whb: 0 = TFA_2-family windows, 1 = WHB windows (a launch runs one kind of biquad window)
 	for (int q = 4 + 2 * whb; q < 6 + 2 * whb; q++) {
 		const uint32_t count = T.queue[q].count;
 		while (true) {
@@ -502,7 +502,7 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 __global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							int32_t *__restrict__ dev32, int lanes)
+							int32_t *__restrict__ dev32, int lanes, int want_kind)
 {
 	const int a = blockIdx.y;
 	const int s = blockIdx.x * lanes + threadIdx.x;
@@ -510,6 +510,8 @@ __global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restri
 		return;
 	const int M = n_blocks * kBlockDec;
 	const int kind = L.params[a].kind;
+	if (kind != want_kind)
+		return;
 	if (kind == 1)
 		fix_chain<false>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 	else if (kind == 2)
@@ -1265,32 +1267,46 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	mark(0, st);
 	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
 	mark(1, st);
-	hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, fmdev, fmdev_stride,
-			   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-	mark(2, st);
-	hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks, L,
-			   T, ld16, dev32, lanes_chain);
-	mark(3, st);
-	// The WHB chain (stage 2) and the TFA chains (slicers + commit) touch disjoint state: run them side by side.
+	// Two independent kernel chains after the window scan (they touch disjoint state):
+	//   aux stream : WHB   spec_biquad -> fix_biquad -> whb_kernel            (the long pole: starts first)
+	//   main stream: TFA   spec_biquad -> fix_biquad -> slicer_kernel -> commit_kernel
+	bool has_whb = false, has_tfa2 = false;
+	for (int a = 0; a < L.n_active; a++) {
+		has_whb = has_whb || L.params[a].kind == 2;
+		has_tfa2 = has_tfa2 || L.params[a].kind == 1;
+	}
 	bool forked = false;
-	for (int a = 0; a < L.n_active; a++)
-		if (L.params[a].kind == 2) {
-			hipStream_t ws = st;
-			if (aux && !forked) {
-				if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess)
-					return e;
-				forked = true;
-			}
-			if (forked)
-				ws = aux;
-			mark(6, ws);
-			hipLaunchKernelGGL(whb_kernel, dim3((n_streams + lanes_whb - 1) / lanes_whb), block, 0, ws, dec, dec_stride,
-					   dev32, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, lanes_whb,
-					   env_int("TFREC_AMD_ABLATE", 64) & 63);
-			mark(7, ws);
+	if (has_whb) {
+		hipStream_t ws = st;
+		if (aux) {
+			if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess)
+				return e;
+			forked = true;
+			ws = aux;
 		}
-	if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
-		return e;
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 1);
+		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
+				   L, T, ld16, dev32, lanes_chain, 2);
+		mark(6, ws);
+		for (int a = 0; a < L.n_active; a++)
+			if (L.params[a].kind == 2)
+				hipLaunchKernelGGL(whb_kernel, dim3((n_streams + lanes_whb - 1) / lanes_whb), block, 0, ws, dec, dec_stride,
+						   dev32, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, lanes_whb,
+						   env_int("TFREC_AMD_ABLATE", 64) & 63);
+		mark(7, ws);
+		if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
+			return e;
+	}
+	if (has_tfa2) {
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0);
+		mark(2, st);
+		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
+				   L, T, ld16, dev32, lanes_chain, 1);
+	} else
+		mark(2, st);
+	mark(3, st);
 	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
 			   lanes_win);
 	mark(4, st);
