@@ -61,7 +61,8 @@ enum {
 typedef struct {
 	int32_t n_streams;   /* independent IQ streams in the batch (>=1) */
 	int32_t types_mask;  /* bit n = sensor_e n as main.cpp -T: TFA_1 0x01, TFA_2 0x02, TFA_3 0x04, TX22 0x08, WHB 0x20 */
-	int32_t thresh;      /* trigger threshold, main.cpp -t (fixed; the reference's auto mode 0 is not offered yet) */
+	int32_t thresh;      /* trigger threshold, main.cpp -t; 0 = the reference's auto mode (starts at 500, adapts by +-2
+				every 4th block, fm_demod.cpp:23-27, 58-73) */
 	int32_t filter_type; /* 0 = narrow, 1 = wide (-W), dsp_stuff.cpp:176-178 */
 	int32_t device;      /* HIP device ordinal */
 	int32_t max_blocks;  /* largest n_blocks a submit may carry (sizes the device buffers) */
@@ -130,6 +131,8 @@ int tfrec_amd_read_decimated(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_
 /* Samples whose FM-discriminator truncation was closer than 1e-9 to an integer boundary. */
 int tfrec_amd_atan_uncertain(tfrec_amd_ctx *ctx, uint64_t *n);
 int tfrec_amd_get_timings(tfrec_amd_ctx *ctx, tfrec_amd_timings *out);
+/* Current trigger threshold of one stream (auto mode moves it; fixed mode returns cfg.thresh). */
+int tfrec_amd_read_thresh(tfrec_amd_ctx *ctx, int stream, int *thresh);
 
 #ifdef __cplusplus
 }

@@ -33,8 +33,8 @@ def test_argument_validation_precedes_device_use():
     h = C.c_void_p()
     bad = api.Config(0, 0x2F, 500, 0, 0, 8, 1024, 0)  # n_streams = 0
     assert L.tfrec_amd_create(C.byref(bad), C.byref(h)) == api.E_INVAL
-    auto = api.Config(4, 0x2F, 0, 0, 0, 8, 1024, 0)  # auto threshold not offered
-    assert L.tfrec_amd_create(C.byref(auto), C.byref(h)) == api.E_INVAL
+    neg = api.Config(4, 0x2F, -1, 0, 0, 8, 1024, 0)  # negative threshold (0 = the reference's auto mode is valid)
+    assert L.tfrec_amd_create(C.byref(neg), C.byref(h)) == api.E_INVAL
     assert L.tfrec_amd_create(None, C.byref(h)) == api.E_INVAL
     assert L.tfrec_amd_destroy(None) == api.E_OK
     assert L.tfrec_amd_strerror(api.E_OVERFLOW) == b"event buffer overflow"

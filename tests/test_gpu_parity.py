@@ -166,3 +166,29 @@ def test_stress_sporadic_triggers(serial, thresh):
         for s in range(n_streams):
             total += check_stream(ev, s, oracle_events(iq[s], 0x2F, thresh))
         assert total > 500
+
+
+@SERIAL
+def test_auto_threshold_matches_oracle(serial):
+    """-t 0: the reference's adaptive trigger threshold (fm_demod.cpp:23-27, 58-73), block by block."""
+    n_blocks = 48
+    rows = [synth.gen_stream(7, 3, n_blocks, 0x1F, 512),    # the golden auto-threshold case of streams.json
+            synth.gen_stream(19, 1, n_blocks, 0x1F, 1536),   # noisier: threshold climbs
+            synth.gen_stream(19, 2, n_blocks, 0x1F, 64),     # quiet: threshold falls to its floor region
+            synth.gen_stream(19, 3, n_blocks, 0x00, 2048)]
+    iq = np.stack(rows)
+    with api.Receiver(iq.shape[0], 0x2F, 0, 0, max_blocks=20, all_flushes=True, serial_chains=serial,
+                      max_events=200000) as r:
+        evs = []
+        for a, b in ((0, 20), (20, 33), (33, 48)):  # thresholds must carry across submits
+            r.submit(np.ascontiguousarray(iq[:, a * 65536:b * 65536]))
+            evs.append(r.drain())
+        ev = np.concatenate(evs)
+        ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
+        moved = 0
+        for s in range(iq.shape[0]):
+            o = oracle_events(iq[s], 0x2F, 0)
+            check_stream(ev, s, o)
+            assert r.thresh(s) == o.thresh(), "stream %d" % s
+            moved += int(o.thresh() != 500)
+        assert moved >= 2

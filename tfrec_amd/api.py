@@ -69,7 +69,7 @@ EXPORTS = (
     "tfrec_amd_version", "tfrec_amd_strerror", "tfrec_amd_last_error", "tfrec_amd_create", "tfrec_amd_destroy",
     "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
-    "tfrec_amd_get_timings",
+    "tfrec_amd_get_timings", "tfrec_amd_read_thresh",
 )
 
 _lib = None
@@ -115,6 +115,7 @@ def load_library(build: bool = True):
     L.tfrec_amd_read_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.tfrec_amd_atan_uncertain.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tfrec_amd_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    L.tfrec_amd_read_thresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -206,6 +207,11 @@ class Receiver:
         n = C.c_uint64(0)
         _check(self.L, self.L.tfrec_amd_atan_uncertain(self.h, C.byref(n)))
         return int(n.value)
+
+    def thresh(self, stream: int) -> int:
+        v = C.c_int(0)
+        _check(self.L, self.L.tfrec_amd_read_thresh(self.h, stream, C.byref(v)))
+        return int(v.value)
 
     def timings(self) -> dict:
         t = Timings()

@@ -19,6 +19,8 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
 			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev);
+hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stride, unsigned long long *mask,
+			    size_t mask_stride, int n_streams, int n_blocks, FskState *fsk, int wmax);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			 size_t mask_stride, int n_streams, int n_blocks, long long sample_base, const ChainLaunch &L,
 			 tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
@@ -53,7 +55,8 @@ struct tfrec_amd_ctx {
 	int32_t *d_dev32 = nullptr;  // [n_streams][m_max] WHB stage-1 outputs
 	WinTables win;
 	void *win_block = nullptr;
-	int32_t *h_overflow_dummy = nullptr;
+	FskState *d_fsk = nullptr;  // auto-threshold mode only
+	int wmax = 0;
 	uint8_t *d_tail[2] = { nullptr, nullptr };
 	int tail_sel = 0;
 	tfrec_amd_event *d_events = nullptr;
@@ -158,6 +161,7 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_ld16);
 	(void)hipFree(c->d_dev32);
 	(void)hipFree(c->win_block);
+	(void)hipFree(c->d_fsk);
 	(void)hipFree(c->d_tail[0]);
 	(void)hipFree(c->d_tail[1]);
 	(void)hipFree(c->d_events);
@@ -190,9 +194,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		snprintf(g_err, sizeof(g_err), "bad config");
 		return TFREC_AMD_E_INVAL;
 	}
-	if (cfg->thresh <= 0) {
-		// fm_demod.cpp:23-27 turns 0 into the adaptive mode; that per-block feedback loop is SURVEY 8(f2)
-		snprintf(g_err, sizeof(g_err), "thresh must be > 0 (auto threshold mode not available)");
+	if (cfg->thresh < 0) {
+		snprintf(g_err, sizeof(g_err), "thresh must be >= 0 (0 = the reference's auto mode)");
 		return TFREC_AMD_E_INVAL;
 	}
 	int ndev = 0;
@@ -276,6 +279,16 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	c->mask_stride = m_max / 64;
 	ALLOC(c->d_dec, n * c->dec_stride * sizeof(uint32_t) + 256);  // + slack: K3 loads whole 32-sample chunks at window tails
 	ALLOC(c->d_mask, n * c->mask_stride * sizeof(unsigned long long));
+	for (int a = 0; a < c->launch.n_active; a++)
+		c->wmax = std::max(c->wmax, (int)c->launch.params[a].window);
+	if (cfg->thresh == 0) {  // fm_demod.cpp:23-27: 0 selects the adaptive mode starting at 500
+		ALLOC(c->d_fsk, n * sizeof(FskState));
+		if (rc == TFREC_AMD_OK) {
+			std::vector<FskState> init(n, FskState{ 500, 0, 0, -(1 << 28) });
+			if (hipMemcpy(c->d_fsk, init.data(), n * sizeof(FskState), hipMemcpyHostToDevice) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+		}
+	}
 	ALLOC(c->d_fmdev, n * m_max * sizeof(int16_t) + 256);  // + slack: K3 reads whole dwords past an odd tail
 	if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
 		// window-parallel pipeline buffers (chains2.hip)
@@ -377,7 +390,10 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 		HIPCHK(hipEventRecord(c->ev[0], st));
 	HIPCHK(launch_frontend(st, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
 			       c->d_tail[c->tail_sel ^ 1], c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev,
-			       c->dec_stride, c->d_eb, c->cfg.thresh, c->taps));
+			       c->dec_stride, c->d_eb, c->cfg.thresh ? c->cfg.thresh : 500, c->taps));
+	if (c->d_fsk)  // auto threshold: per-block thresholds rewrite the trigger mask (fm_demod.cpp:58-73)
+		HIPCHK(launch_threshold(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
+					c->d_fsk, c->wmax));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[1], st));
 	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)
@@ -510,6 +526,23 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 	EventBuf eb;
 	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
 	*n = c->uncertain_total + eb.uncertain;
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_read_thresh(tfrec_amd_ctx *c, int stream, int *thresh)
+{
+	if (!c || !thresh || stream < 0 || stream >= c->cfg.n_streams)
+		return TFREC_AMD_E_INVAL;
+	if (!c->d_fsk) {
+		*thresh = c->cfg.thresh;
+		return TFREC_AMD_OK;
+	}
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	FskState f;
+	HIPCHK(hipMemcpy(&f, c->d_fsk + stream, sizeof(f), hipMemcpyDeviceToHost));
+	*thresh = f.thresh;
 	return TFREC_AMD_OK;
 }
 

@@ -83,6 +83,67 @@ struct BitWriter {
 	}
 };
 
+// ------------------------------------------------------------------------------------------------ K1b auto threshold
+// fsk_demod::process in auto mode (thresh_mode == 1, fm_demod.cpp:58-73): per block of 8192 decimated samples
+//   triggered     = samples at which at least one demodulator is inside its window
+//   triggered_avg = (31*triggered_avg + triggered)/32;   every 4th block: avg >= len/32 -> thresh += 2,
+//                   avg <= len/64 && thresh > 50 -> thresh -= 2          (len = 16384)
+// The threshold of block b+1 depends on block b, so a stream is scanned block by block; all demodulators use
+// the same trigger test, so "some demodulator is in its window" = "within Wmax samples after a trigger" with Wmax
+// the largest window of the registered demodulators.  One wave per stream: 64 samples per step (coalesced),
+// ballot -> mask word, wave-uniform bookkeeping.  Rewrites the trigger mask the front end produced.
+__global__ __launch_bounds__(64) void threshold_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+						       unsigned long long *__restrict__ mask, size_t mask_stride, int n_blocks,
+						       FskState *__restrict__ fsk, int wmax)
+{
+	const int s = blockIdx.x;
+	const int lane = threadIdx.x;
+	const uint32_t *drow = dec + (size_t)s * dec_stride;
+	unsigned long long *mrow = mask + (size_t)s * mask_stride;
+	FskState st = fsk[s];
+	int last_trig = st.last_trig;  // relative to sample 0 of this submit (very negative: none)
+	for (int b = 0; b < n_blocks; b++) {
+		int triggered = 0;
+		st.runs++;
+		for (int w = b * (kBlockDec / 64); w < (b + 1) * (kBlockDec / 64); w++) {
+			const uint32_t cw = drow[(w << 6) + lane];
+			const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
+			const unsigned long long m = __ballot((abs(I) + abs(Q)) > st.thresh);
+			if (lane == 0)
+				mrow[w] = m;
+			// samples of this word that lie within wmax after the last trigger (windows are >= 355 > 64 long:
+			// everything after the word's first trigger is inside)
+			const int g0 = w << 6;
+			const int first = m ? __builtin_ctzll(m) : 64;
+			int carried = last_trig + wmax - g0;  // samples from g0 on still covered by the earlier trigger
+			carried = carried < 0 ? 0 : (carried > first ? first : carried);
+			triggered += carried + (64 - first);
+			if (m)
+				last_trig = g0 + 63 - __builtin_clzll(m);
+		}
+		st.triggered_avg = (31 * st.triggered_avg + triggered) / 32;
+		if ((st.runs & 3) == 0) {
+			if (st.triggered_avg >= kIndexSpan / 32)
+				st.thresh += 2;
+			else if (st.triggered_avg <= kIndexSpan / 64 && st.thresh > 50)
+				st.thresh -= 2;
+		}
+	}
+	if (lane == 0) {
+		const int M = n_blocks * kBlockDec;
+		st.last_trig = last_trig - M < -(1 << 28) ? -(1 << 28) : last_trig - M;
+		fsk[s] = st;
+	}
+}
+
+hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stride, unsigned long long *mask,
+			    size_t mask_stride, int n_streams, int n_blocks, FskState *fsk, int wmax)
+{
+	hipLaunchKernelGGL(threshold_kernel, dim3(n_streams), dim3(64), 0, st, dec, dec_stride, mask, mask_stride, n_blocks, fsk,
+			   wmax);
+	return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ K2
 // One WAVE per stream: 64 mask words are loaded coalesced per step, a ballot finds the non-zero ones, and
 // a wave-uniform scalar walk over runs of non-zero words maintains, for every active slot of the stream, the

@@ -77,6 +77,14 @@ struct ChainLaunch {
 	ChainParams params[kNSlots];
 };
 
+// fsk_demod state of one stream in auto-threshold mode (fm_demod.h:23-30, fm_demod.cpp:18-32)
+struct FskState {
+	int32_t thresh;         // current trigger threshold
+	int32_t triggered_avg;  // fm_demod.cpp:58
+	int32_t runs;           // blocks processed so far (fm_demod.cpp:37)
+	int32_t last_trig;      // last sample with pwr > thresh, relative to the start of the current submit
+};
+
 struct EventBuf {
 	uint32_t count;     // events appended (may exceed capacity -> overflow)
 	uint32_t capacity;

@@ -4,7 +4,7 @@
 //   tfrec_gpu [-T hexmask] -X telegrams.txt
 //
 // Flags keep the reference's meaning (main.cpp:63-88, 107-164): -T sensor type bit mask (hex), -t trigger
-// threshold (fixed; 0/auto is not offered on the GPU path yet), -W wide filter, -q quiet, -D debug,
+// threshold (0 = auto, the default), -W wide filter, -q quiet, -D debug,
 // -L raw 8-bit IQ dump as written by "tfrec -S", -X hex telegrams for the byte-level test entry
 // (main.cpp:24-53).  Several -L files are processed as one batch, one stream each.
 #include <stdio.h>
@@ -52,7 +52,7 @@ static int replay_hex(int types, int dbg, const char *fn)
 
 int main(int argc, char **argv)
 {
-	int types = 0x07, thresh = 500, filter = 0, dbg = 0, device = 0, blocks = 16;
+	int types = 0x07, thresh = 0, filter = 0, dbg = 0, device = 0, blocks = 16;  // defaults of main.cpp:97-105 (0 = auto)
 	std::vector<std::string> dumps;
 	const char *hexfile = NULL;
 	int c;
@@ -79,8 +79,8 @@ int main(int argc, char **argv)
 		fprintf(stderr, "tfrec_gpu: need -L <dumpfile> or -X <hexfile>\n");
 		return 1;
 	}
-	if (thresh <= 0) {
-		fprintf(stderr, "tfrec_gpu: -t must be > 0 (the reference's auto threshold is not available on the GPU path)\n");
+	if (thresh < 0) {
+		fprintf(stderr, "tfrec_gpu: -t must be >= 0 (0 = auto)\n");
 		return 1;
 	}
 	gpu_engine e(dumps, types, thresh, filter, dbg, device, blocks);
