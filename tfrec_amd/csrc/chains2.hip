@@ -173,23 +173,52 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 		last_trig[a] = open[a] ? t0[a] - W[a] : -(1 << 29);  // virtual trigger leaving t0 samples of window
 		count[a] = 0;
 	}
-	auto emit = [&](int a, int og, int close) {
-		if (lane != 0)
+	// work items are collected per wave in LDS and handed to the global queues with ONE atomic per queue and
+	// flush (thousands of waves pushing single items contend on a handful of counters otherwise)
+	constexpr int kLocal = 256;
+	__shared__ uint2 litems[kNQueues][kLocal];
+	int lcount[kNQueues];
+#pragma unroll
+	for (int q = 0; q < kNQueues; q++)
+		lcount[q] = 0;
+	auto flush_one = [&](int q, int &nq) {  // wave-uniform, q is a compile-time constant at every call site
+		if (nq == 0)
 			return;
+		uint32_t base0 = 0;
+		if (lane == 0)
+			base0 = atomicAdd(&T.queue[q].count, (uint32_t)nq);
+		base0 = __builtin_amdgcn_readfirstlane(base0);
+		for (int k = lane; k < nq; k += 64)
+			T.items[(size_t)q * total + base0 + k] = litems[q][k];
+		nq = 0;
+	};
+	auto push = [&](int q, uint2 it) {  // wave-uniform; static indexing keeps lcount[] in registers
+#pragma unroll
+		for (int qq = 0; qq < kNQueues; qq++)
+			if (qq == q) {
+				if (lcount[qq] == kLocal)
+					flush_one(qq, lcount[qq]);
+				if (lane == 0)
+					litems[qq][lcount[qq]] = it;
+				lcount[qq]++;
+			}
+	};
+	auto emit = [&](int a, int og, int close) {
 		const int c = a * n_streams + s;
 		if (count[a] < T.cap) {
-			T.open[(size_t)c * T.cap + count[a]] = og;
-			T.close[(size_t)c * T.cap + count[a]] = close;
+			if (lane == 0) {
+				T.open[(size_t)c * T.cap + count[a]] = og;
+				T.close[(size_t)c * T.cap + count[a]] = close;
+			}
 			const int kind = L.params[a].kind;
 			const int last = close < M ? close : M - 1;
-			const int lng = (last - og + 1) >= kLongWindow ? 0 : 1;
-			if (kind < 2) {  // slicer work item
-				const uint32_t idx = atomicAdd(&T.queue[2 * kind + lng].count, 1u);
-				T.items[(size_t)(2 * kind + lng) * total + idx] = make_uint2((uint32_t)c, (uint32_t)count[a]);
-			}
-			if (kind > 0) {  // the chain owns a biquad: speculative window run (K3a); 4,5: TFA_2 family; 6,7: WHB
-				const uint32_t idx = atomicAdd(&T.queue[2 + 2 * kind + lng].count, 1u);
-				T.items[(size_t)(2 + 2 * kind + lng) * total + idx] = make_uint2((uint32_t)c, (uint32_t)count[a]);
+			const int n = last - og + 1;
+			if (kind < 2)  // slicer work item: queues 2*kind + {0 long, 1 short}
+				push(2 * kind + (n >= kLongWindow ? 0 : 1), make_uint2((uint32_t)c, (uint32_t)count[a]));
+			if (kind > 0) {  // the chain owns a biquad: one speculative item per segment; queue 4: TFA_2 family, 6: WHB
+				const int nseg = (n + kSegSamples - 1) / kSegSamples;
+				for (int sg = 0; sg < nseg; sg++)
+					push(2 + 2 * kind, make_uint2((uint32_t)c | ((uint32_t)sg << 19), (uint32_t)count[a]));
 			}
 		} else
 			overflow = true;
@@ -244,6 +273,9 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 			}
 		}
 	}
+#pragma unroll
+	for (int q = 0; q < kNQueues; q++)
+		flush_one(q, lcount[q]);
 	if (overflow && lane == 0)
 		*T.overflow = 1;
 }
@@ -408,7 +440,7 @@ __device__ __forceinline__ void k3_store(void *outrow, int slot, const uint32_t 
 }
 
 template <bool WHB>
-__device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
+__device__ __forceinline__ void spec_window(int c, int j, int seg, int n_streams, int M, const uint32_t *__restrict__ dec,
 					    size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
 					    const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
 					    int32_t *__restrict__ dev32)
@@ -421,20 +453,22 @@ __device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, 
 	const int n = (close < M ? close : M - 1) - og + 1;
 	const BiquadCoef cf = p.iir;
 	Biquad f;
-	if (j == 0)
-		f = st.iir;  // the chain's first window starts from the true carried state
+	if (j == 0 && seg == 0)
+		f = st.iir;  // the chain's first segment starts from the true carried state
 	else
-		f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
+		f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;  // speculation: fix_biquad_kernel repairs the head of the segment
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
 	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
 	const int slot0 = win_slot0(og, j);
 	const int nchunks = (n + kChunk - 1) >> 5;
-	unsigned long long pw = 0;
+	const int i0 = seg * kSegSlots;
+	const int i1 = nchunks < i0 + kSegSlots ? nchunks : i0 + kSegSlots;
+	unsigned long long pw = 0;  // power prefix, local to the segment
 	K3Chunk<WHB> A, B;
-	k3_load<WHB>(A, in, og, prev0);
-	for (int i = 0; i < nchunks; i += 2) {
-		if (i + 1 < nchunks)
+	k3_load<WHB>(A, in, og + kChunk * i0, prev0);
+	for (int i = i0; i < i1; i += 2) {
+		if (i + 1 < i1)
 			k3_load<WHB>(B, in, og + kChunk * (i + 1), prev0);
 		{
 			uint32_t ow[WHB ? 32 : 16];
@@ -445,9 +479,9 @@ __device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, 
 			if (WHB)
 				T.pw[(size_t)s * T.slots + slot0 + i] = pw;
 		}
-		if (i + 1 >= nchunks)
+		if (i + 1 >= i1)
 			break;
-		if (i + 2 < nchunks)
+		if (i + 2 < i1)
 			k3_load<WHB>(A, in, og + kChunk * (i + 2), prev0);
 		{
 			uint32_t ow[WHB ? 32 : 16];
@@ -459,11 +493,13 @@ __device__ __forceinline__ void spec_window(int c, int j, int n_streams, int M, 
 				T.pw[(size_t)s * T.slots + slot0 + i + 1] = pw;
 		}
 	}
-	BiquadEnd &we = T.wend[(size_t)c * T.cap + j];
-	we.dn1 = f.dn1;
-	we.dn2 = f.dn2;
-	we.yn = f.yn;
-	we.yn1 = f.yn1;
+	if (i1 == nchunks) {  // the window's last segment: its end state in full
+		BiquadEnd &we = T.wend[(size_t)c * T.cap + j];
+		we.dn1 = f.dn1;
+		we.dn2 = f.dn2;
+		we.yn = f.yn;
+		we.yn1 = f.yn1;
+	}
 }
 
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
@@ -483,11 +519,11 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 			if (idx >= count)
 				break;
 			const uint2 it = T.items[(size_t)q * total + idx];
-			const int c = (int)it.x, j = (int)it.y;
+			const int c = (int)(it.x & 0x7ffffu), seg = (int)(it.x >> 19), j = (int)it.y;
 			if (whb)
-				spec_window<true>(c, j, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+				spec_window<true>(c, j, seg, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 			else
-				spec_window<false>(c, j, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+				spec_window<false>(c, j, seg, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 		}
 	}
 }
@@ -508,32 +544,62 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
 	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
-	BiquadEnd tr = T.wend[(size_t)c * T.cap];  // window 0 ran from the true state
-	Biquad f;
+	// biquad input of sample g (to rebuild dn1/dn2 at the end of a segment)
+	auto input_at = [&](int g) -> double {
+		if (WHB) {
+			const uint32_t *drow = static_cast<const uint32_t *>(in);
+			const uint32_t cw = drow[g], pw = g > 0 ? drow[g - 1] : prev0;
+			return (double)fm_dev_nrzs((int)(int16_t)(cw & 0xffff), (int)cw >> 16, (int)(int16_t)(pw & 0xffff), (int)pw >> 16);
+		}
+		return (double)static_cast<const int16_t *>(in)[g];
+	};
+	Biquad f;  // the TRUE filter state while walking the chain
 	f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
-	// flat loop over (window, chunk); the chunk after the current one (same window) is always in flight
-	int j = 0, i = 0, nchunks = 0, og = 0, n = 0, slot0 = 0;
+	// state at the end of segment (j, seg) of the stored trajectory (exact once the segment is exact / converged)
+	auto seg_end = [&](int og, int slot0, int j, int seg, bool last_seg) -> Biquad {
+		Biquad r;
+		if (last_seg) {
+			const BiquadEnd e = T.wend[(size_t)c * T.cap + j];
+			r.dn1 = e.dn1; r.dn2 = e.dn2; r.yn = e.yn; r.yn1 = e.yn1;
+		} else {  // a full segment of kSegSamples (>= 2) samples
+			const int r_end = (seg + 1) * kSegSamples - 1;
+			const double2 ck = T.ckpt[(size_t)c * T.slots + slot0 + (r_end >> 5)];
+			r.yn = ck.x; r.yn1 = ck.y;
+			r.dn1 = input_at(og + r_end);
+			r.dn2 = input_at(og + r_end - 1);
+		}
+		return r;
+	};
+	// flat loop over (window, segment, chunk); the chunk after the current one is always in flight
+	int j = -1, seg = 0, nseg = 0, i = 0, iend = 0, og = 0, n = 0, slot0 = 0, nchunks = 0;
+	bool fixing = false, last_seg = false;
 	K3Chunk<WHB> A, B;
 	double2 ckA = make_double2(0, 0), ckB = make_double2(0, 0);
 	while (true) {
-		if (i >= nchunks) {
-			if (j > 0 && nchunks > 0) {  // window j ended without convergence: its true end state is ours
-				tr.dn1 = f.dn1; tr.dn2 = f.dn2; tr.yn = f.yn; tr.yn1 = f.yn1;
-				T.wend[(size_t)c * T.cap + j] = tr;
+		if (!fixing) {
+			if (++seg >= nseg) {
+				if (++j >= count)
+					break;
+				og = T.open[(size_t)c * T.cap + j];
+				const int close = T.close[(size_t)c * T.cap + j];
+				n = (close < M ? close : M - 1) - og + 1;
+				nchunks = (n + kChunk - 1) >> 5;
+				slot0 = win_slot0(og, j);
+				nseg = (n + kSegSamples - 1) / kSegSamples;
+				seg = 0;
 			}
-			if (++j >= count)
-				break;
-			og = T.open[(size_t)c * T.cap + j];
-			const int close = T.close[(size_t)c * T.cap + j];
-			n = (close < M ? close : M - 1) - og + 1;
-			nchunks = (n + kChunk - 1) >> 5;
-			slot0 = win_slot0(og, j);
-			i = 0;
-			f.dn1 = tr.dn1; f.dn2 = tr.dn2; f.yn = tr.yn; f.yn1 = tr.yn1;
-			k3_load<WHB>(A, in, og, prev0);
-			ckA = T.ckpt[(size_t)c * T.slots + slot0];
+			last_seg = seg == nseg - 1;
+			if (j == 0 && seg == 0) {  // ran from the true carried state: already exact
+				f = seg_end(og, slot0, j, seg, last_seg);
+				continue;
+			}
+			i = seg * kSegSlots;
+			iend = nchunks < i + kSegSlots ? nchunks : i + kSegSlots;
+			k3_load<WHB>(A, in, og + kChunk * i, prev0);
+			ckA = T.ckpt[(size_t)c * T.slots + slot0 + i];
+			fixing = true;
 		}
-		const int inext = i + 1 < nchunks ? i + 1 : i;
+		const int inext = i + 1 < iend ? i + 1 : i;
 		k3_load<WHB>(B, in, og + kChunk * inext, prev0);
 		ckB = T.ckpt[(size_t)c * T.slots + slot0 + inext];
 		uint32_t ow[WHB ? 32 : 16];
@@ -543,21 +609,24 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 		k3_store<WHB>(out, slot0 + i, ow);
 		// bit-for-bit state match with the speculative run?  (the two last inputs are shared once 2 samples in)
 		const bool same = __double_as_longlong(f.yn) == __double_as_longlong(ckA.x) &&
-				  __double_as_longlong(f.yn1) == __double_as_longlong(ckA.y) && (kChunk * i + nv) >= 2;
+				  __double_as_longlong(f.yn1) == __double_as_longlong(ckA.y) &&
+				  (kChunk * (i - seg * kSegSlots) + nv) >= 2;
 		if (same) {
-			tr = T.wend[(size_t)c * T.cap + j];  // the rest of the speculative run is exact
-			nchunks = 0;                         // -> next window, without the "not converged" path
-			i = 0;
+			f = seg_end(og, slot0, j, seg, last_seg);  // the rest of the segment's speculative run is exact
+			fixing = false;
+		} else if (++i >= iend) {  // the segment ended without convergence: f IS its true end state
+			if (last_seg) {
+				BiquadEnd e;
+				e.dn1 = f.dn1; e.dn2 = f.dn2; e.yn = f.yn; e.yn1 = f.yn1;
+				T.wend[(size_t)c * T.cap + j] = e;
+			}
+			fixing = false;
 		} else {
-			i++;
 			A = B;
 			ckA = ckB;
 		}
 	}
-	st.iir.dn1 = tr.dn1;
-	st.iir.dn2 = tr.dn2;
-	st.iir.yn = tr.yn;
-	st.iir.yn1 = tr.yn1;
+	st.iir = f;
 }
 
 __global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
@@ -995,11 +1064,19 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 	const int count = T.count[c];
 	const bool cont = T.cont[c] != 0;
 
-	// power prefix of the window up to and including window-relative sample r (this submit)
+	// K3a stores the power prefix per slot, restarting at every kSegSlots-slot segment of a window:
+	// window-cumulative power up to the END of window-relative slot ci (this submit)
+	auto cum_slot_end = [&](int slot0, int ci) -> unsigned long long {
+		unsigned long long v = pwrow[slot0 + ci];
+		for (int sg = 0; sg < ci / kSegSlots; sg++)
+			v += pwrow[slot0 + kSegSlots * (sg + 1) - 1];
+		return v;
+	};
+	// ... and up to and including window-relative sample r
 	auto prefix_at = [&](int og, int slot0, int r) -> unsigned long long {
 		if (r < 0)
 			return 0ull;
-		unsigned long long v = (r >> 5) > 0 ? pwrow[slot0 + (r >> 5) - 1] : 0ull;
+		unsigned long long v = (r >> 5) > 0 ? cum_slot_end(slot0, (r >> 5) - 1) : 0ull;
 		for (int q = r & ~31; q <= r; q++) {
 			const uint32_t cw = drow[og + q];
 			const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
@@ -1094,7 +1171,7 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 					if (d.synced) {
 						for (int q = 0; q < 16; q++)
 							store_bit<2>(d, 0);
-						const unsigned long long tot = pwrow[slot0 + i];
+						const unsigned long long tot = cum_slot_end(slot0, i);
 						flush<2>(e, d, (long long)(rssi_d + (double)(tot - rssi_base)), 0, og + n - 1);
 					}
 					rssi_d = 0;
@@ -1103,7 +1180,7 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 					last_peak = 0;
 				} else {  // window continues in the next submit
 					if (d.synced)
-						rssi_d += (double)(pwrow[slot0 + i] - rssi_base);
+						rssi_d += (double)(cum_slot_end(slot0, i) - rssi_base);
 					rssi_base = 0;
 					step0 += n;
 				}

@@ -136,6 +136,8 @@ struct WinTables {
 };
 
 constexpr int kNQueues = 8;
+constexpr int kSegSlots = 128;                   // speculative biquad segments: 128 slots = 4096 samples
+constexpr int kSegSamples = kSegSlots * 32;
 constexpr int kLongWindow = 6000;  // samples; longer windows are handed out first (tail balance)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
