@@ -18,9 +18,10 @@
 //                       influence a window through its first candidate edge, so windows are run assuming a
 //                       far-away last edge and the assumption is checked (and the window re-run exactly) in K5.
 //                       Output: the bits handed to decoder::store_bit, packed.
-//   K4' whb_kernel      lane per stream: WHB stage 2 (decision-level biquad, phase-change detector, decoder);
-//                       demodulator and decoder feed back into each other through has_sync() (whb.cpp:653,
-//                       677, 693), so this chain stays serial.
+//   K4' whb_demod_kernel  32 lanes per stream: WHB stage 2 (decision-level biquad, phase-change detector); the
+//                       demodulator needs the decoder's has_sync() (whb.cpp:653, 677, 693), which is tracked
+//                       with a lane-parallel evaluation of the (GF(2)-linear) sync search.  Output: bit runs.
+//   K4'' whb_commit_kernel lane per stream: whb_decoder::store_bit over the runs, flush events.
 //   K5 commit_kernel    lane per (stream, slot): walks the windows in order: validates/repairs the tfa2
 //                       speculation, runs the decoders (store_bit / flush) over the packed bits with their
 //                       persistent state (sr, rdata), emits events, commits ChainState for the next submit.
@@ -939,117 +940,48 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ K4' WHB stage 2
-// Serial lane per stream (demodulator and decoder feed back through has_sync(), whb.cpp:653/677/693).
-// Per 32-sample slot of stage-1 output: (1) a branch-free pass steps the decision-level biquad (only while the
-// decoder is unsynced) and collects the "local minimum below average" candidates (whb.cpp:662-663) in a bit
-// mask; (2) an event loop visits only the candidates that also satisfy the 3/4-bit spacing rule (:664), emits
-// their bits through the decoder, and -- if the decoder locks in the middle of a slot -- rewinds the slot to
-// that sample and redoes the rest in synced mode.  The RSSI sum of a synced interval (:678) is an exact
-// integer, so it is taken as a difference of the power prefix K3a stored per slot.
-struct WhbFast {
-	Biquad iir_avg;
-	int avg_of, last_dev;
-};
+// whb_demod::demod after the first low-pass (whb.cpp:653-703), wave-cooperative: 32 lanes per stream, two streams
+// per wave.  With only ~1000 streams a lane-per-stream kernel is bound by the issue rate of a lone wave (one
+// instruction per ~4.5 cycles, whatever the number of active lanes), so the per-sample instruction count of the
+// SERIAL part is what matters.  Per 32-sample slot of stage-1 output the lanes therefore split the work:
+//   (1) lane n owns sample n: it forms the feed-forward half of the decision-level biquad for its sample,
+//       P(n) = fl(b0*dn + b1*dn1) and B2(n) = fl(b2*dn2) (exactly the two sub-sums of iir_step), into LDS;
+//   (2) every lane runs the 32-step feedback recurrence y = ((B2 + a1*y1) + P) + a2*y2 redundantly (5 fp64
+//       operations + one broadcast LDS read + one LDS write per sample -- the only serial work), only while the
+//       decoder is unsynced (whb.cpp:653);
+//   (3) lane n reads back y(n) -> avg_of(n), tests "local minimum below average" (whb.cpp:662-663), and a ballot
+//       gives the slot's candidate mask;
+//   (4) the (sparse) candidates that pass the 3/4-bit spacing rule (:664) are turned into runs "0,1,1,..";
+//       has_sync() (:653/:677/:693) is tracked by evaluating the decoder's sync word for all positions of a
+//       run at once, one position per lane.  Since psk/nrzs/lfsr/sr are GF(2)-linear in the emitted bits
+//       (nrzs(t) = bit(t) ^ K, out(t) = nrzs(t) ^ nrzs(t-12) ^ nrzs(t-17)), this needs no per-bit loop.
+// When the decoder locks at sample k of a slot the recurrence output y(0..k) is already in LDS: the filter
+// state is taken at k and the candidates after k are re-tested against the frozen average -- no rewind.
+// The runs (one uint16 length per accepted candidate) go to the window's bit region; commit_kernel replays
+// them through whb_decoder::store_bit and reports the flush.  The RSSI sum of a synced interval (:678) is an
+// exact integer, so it is taken as a difference of the power prefix K3a stored per slot.
+constexpr uint32_t kWhbSyncRev = 0xd2b42bd4u;  // bit-reversed 0x2bd42d4b (whb.cpp:582): newest bit at the LSB
+constexpr int kWhbRunEsc = 0xffff;            // run-length escape: the next two uint16 hold a 32-bit length
 
-// One pass over samples [k0, k1] of a slot.  PRED = false: the whole slot (no per-sample tests).
-// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09, so (int) never saturates.
-// One pass over samples [k0, k1] of the lane's slot held in LDS (16-byte piece q of lane L at (q*64+L)*16).
-// Three separate simple loops -- whole slot unsynced (rolled, 4 samples per ds_read_b128), whole slot synced
-// (unrolled compares), partial slot (window tails, rewinds) -- so that the common loops carry no divergent
-// control flow inside and the filter state stays in fixed registers.
-__device__ __forceinline__ uint32_t whb_pass(WhbFast &w, const BiquadCoef &cavg, const uint4 *__restrict__ slot_lds, bool synced,
-					     int k0, int k1)
+__global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
+						       ChainLaunch L, int a, WinTables T)
 {
-	uint32_t mask = 0;
-	const bool full = (k0 == 0) && (k1 == kChunk - 1);
-	if (full && !synced) {
-		Biquad f = w.iir_avg;
-		BiquadT bt = iirt_enter(f, cavg);
-		int avg = w.avg_of, last = w.last_dev;
-		uint4 vn = slot_lds[0];
-#pragma unroll 1
-		for (int q = 0; q < 8; q++) {
-			const uint4 v = vn;
-			vn = slot_lds[((q + 1) & 7) * 64];  // next group's read is in flight while this one is processed
-			const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
-			uint32_t m4 = 0;
-#pragma unroll
-			for (int t = 0; t < 4; t++) {
-				const int dev = (int)dv[t];
-				avg = (int)iir_step_t(f, bt, cavg, 0.5 * (double)dev);      // whb.cpp:653-654
-				m4 |= (uint32_t)(dev < avg && dev > last) << t;             // whb.cpp:662-663
-				last = dev;
-			}
-			mask |= m4 << (4 * q);
-		}
-		w.iir_avg = f;
-		w.avg_of = avg;
-		w.last_dev = last;
-	} else if (full) {
-		const int avg = w.avg_of;
-		int last = w.last_dev;
-#pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const uint4 v = slot_lds[q * 64];
-			const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-			for (int t = 0; t < 4; t++) {
-				const int dev = (int)dv[t];
-				mask |= (uint32_t)(dev < avg && dev > last) << (4 * q + t);
-				last = dev;
-			}
-		}
-		w.last_dev = last;
-	} else {
-#pragma unroll 1
-		for (int q = k0 >> 2; q <= (k1 >> 2); q++) {
-			const uint4 v = slot_lds[q * 64];
-			const uint32_t dv[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-			for (int t = 0; t < 4; t++) {
-				const int k = 4 * q + t;
-				if (k >= k0 && k <= k1) {
-					const int dev = (int)dv[t];
-					if (!synced)
-						w.avg_of = (int)iir_step(w.iir_avg, cavg, 0.5 * (double)dev);
-					mask |= (uint32_t)(dev < w.avg_of && dev > w.last_dev) << k;
-					w.last_dev = dev;
-				}
-			}
-		}
-	}
-	return mask;
-}
-
-__global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
-						 const int32_t *__restrict__ dev32, int n_streams, int n_blocks, long long sample_base,
-						 ChainLaunch L, int a, WinTables T, tfrec_amd_event *__restrict__ events,
-						 EventBuf *__restrict__ eb, uint32_t flags, int lanes, int ablate)
-{
-	const int s = blockIdx.x * lanes + threadIdx.x;
-	if ((int)threadIdx.x >= lanes || s >= n_streams)
-		return;
+	__shared__ double2 pb_lds[64];
+	__shared__ double y_lds[64];
+	const int grp = threadIdx.x >> 5, ln = threadIdx.x & 31;
+	const int s_raw = blockIdx.x * 2 + grp;
+	const bool live = s_raw < n_streams;
+	const int s = live ? s_raw : n_streams - 1;  // a dead half-wave shadows the last stream and never writes
+	double2 *pb = pb_lds + 32 * grp;
+	double *yl = y_lds + 32 * grp;
 	const ChainParams &p = L.params[a];
 	ChainState &st = L.states[a][s];
 	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const uint32_t *dvrow = reinterpret_cast<const uint32_t *>(dev32 + (size_t)s * T.slots * 32);
+	const int32_t *dvrow = dev32 + (size_t)s * T.slots * 32;
 	const unsigned long long *pwrow = T.pw + (size_t)s * T.slots;
-	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
-	// the decoder's persistent rdata[256] lives in LDS while the kernel runs: no global stores in the hot loop
-	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
-	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
-		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
-#pragma unroll
-		for (int q = 0; q < 16; q++)
-			dst[q] = src[q];
-	}
-	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
-	       my_rdata };
-	WhbFast w{ st.iir_avg, st.avg_of, st.last_dev };
 	const BiquadCoef cavg = p.iir_avg;
 	const double spb = p.spb;
 	const double thr = 3 * spb / 4;        // whb.cpp:664
@@ -1058,10 +990,19 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 	const int spb_i = (int)spb;
 	const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
 	const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
+	// ---- per-stream state, replicated in the 32 lanes of the stream
+	Biquad f = st.iir_avg;
+	int avg_of = st.avg_of, last_dev = st.last_dev;
 	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
 	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
 	unsigned long long rssi_base = 0;      // power prefix just before the first synced sample (this submit)
-	const int count = T.count[c];
+	int synced = st.synced;
+	// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
+	// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
+	uint32_t srr = __brev(st.sr);          // whb_decoder::sr, newest bit at the LSB
+	uint32_t nh = st.lfsr;                 // history of nrzs, newest at the LSB (whb.cpp:579)
+	const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
+	const int count = live ? T.count[c] : 0;
 	const bool cont = T.cont[c] != 0;
 
 	// K3a stores the power prefix per slot, restarting at every kSegSlots-slot segment of a window:
@@ -1084,21 +1025,25 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		}
 		return v;
 	};
-	__shared__ uint4 slot_lds[8 * 64];
-	uint4 *my_lds = slot_lds + threadIdx.x;
-	auto load_slot = [&](int slot) -> Slot8 {
-		const uint4 *pv = reinterpret_cast<const uint4 *>(dvrow + (size_t)slot * 32);
-		Slot8 r;
-		r.q0 = pv[0]; r.q1 = pv[1]; r.q2 = pv[2]; r.q3 = pv[3];
-		r.q4 = pv[4]; r.q5 = pv[5]; r.q6 = pv[6]; r.q7 = pv[7];
-		return r;
+	// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
+	auto feed = [&](uint32_t e, int len) -> bool {
+		const uint32_t emask = len >= 32 ? ~0u : (1u << len) - 1u;
+		const uint32_t nrun = __brev((e ^ kmask) & emask) >> (32 - len);           // nrzs of the run, newest at the LSB
+		const unsigned long long hn = ((unsigned long long)nh << len) | nrun;
+		const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;    // descrambled bits, whb.cpp:578
+		const unsigned long long sv = ((unsigned long long)srr << len) | orun;
+		const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
+		const unsigned long long bal = __ballot(hit);
+		nh = (uint32_t)hn;
+		srr = (uint32_t)sv;
+		return ((uint32_t)(bal >> (32 * grp))) != 0u;
 	};
 	struct Win {
 		int og, n, nch, slot0, closed;
 	};
 	auto read_win = [&](int jj) -> Win {
 		Win r;
-		const int jc = jj < count ? jj : count - 1;
+		const int jc = jj < count ? jj : (count > 0 ? count - 1 : 0);
 		r.og = T.open[(size_t)c * T.cap + jc];
 		const int close = T.close[(size_t)c * T.cap + jc];
 		r.closed = close < M;
@@ -1107,85 +1052,149 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 		r.slot0 = win_slot0(r.og, jc);
 		return r;
 	};
-	if (count > 0) {
-		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
-		Slot8 cur = load_slot(cw.slot0);
-		int j = 0, i = 0;
-		while (j < count) {
-			if (!(ablate & 8)) {
-				my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
-				my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
+	Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
+	int j = 0, i = 0, nent = 0;
+	int dev_cur = count > 0 ? dvrow[(size_t)cw.slot0 * 32 + ln] : 0;
+	while (true) {
+		const bool act = j < count;
+		if (__ballot(act) == 0ull)
+			break;
+		// ---- (1) this slot's inputs; the next slot's sample is already in flight
+		const int nv = act ? (cw.n - kChunk * i < kChunk ? cw.n - kChunk * i : kChunk) : 0;
+		const int ns = (i + 1 < cw.nch) ? cw.slot0 + i + 1 : (j + 1 < count ? nw.slot0 : cw.slot0 + i);
+		const int dev_nxt = act ? dvrow[(size_t)ns * 32 + ln] : 0;
+		const int dev = dev_cur;
+		const int devm1 = __shfl_up(dev, 1, 32), devm2 = __shfl_up(dev, 2, 32);
+		const bool rise = dev > (ln >= 1 ? devm1 : last_dev);  // dev > last_dev, whb.cpp:663
+		const bool unsynced0 = act && !synced;
+		const int nv_ser = unsynced0 ? nv : 0;
+		const int nmax = max(__shfl(nv_ser, 0, 64), __shfl(nv_ser, 32, 64));  // wave-uniform
+		int avgn = avg_of;
+		if (nmax > 0) {
+			const double dn = 0.5 * (double)dev;  // whb.cpp:654
+			const double dn1 = ln >= 1 ? 0.5 * (double)devm1 : f.dn1;
+			const double dn2 = ln >= 2 ? 0.5 * (double)devm2 : (ln == 1 ? f.dn1 : f.dn2);
+			pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
+			__syncthreads();
+			// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association)
+			double y1 = f.yn, y2 = f.yn1;
+#pragma unroll 4
+			for (int k = 0; k < nmax; k++) {
+				const double2 v = pb[k];
+				const double y = ((v.y + cavg.a1 * y1) + v.x) + cavg.a2 * y2;
+				yl[k] = y;
+				y2 = y1;
+				y1 = y;
 			}
-			// the slot after this one (same window, else first slot of the next window): in flight during processing
-			const int ns = (i + 1 < cw.nch) ? cw.slot0 + i + 1 : (j + 1 < count ? nw.slot0 : cw.slot0 + i);
-			const Slot8 nxt = load_slot(ns);
+			__syncthreads();
+			// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
+			if (unsynced0)
+				avgn = (int)yl[ln];
+		}
+		// ---- (3) candidates: dev < avg_of && dev > last_dev
+		const unsigned long long bal = __ballot(act && ln < nv && dev < avgn && rise);
+		uint32_t mask = (uint32_t)(bal >> (32 * grp));
+		if (act) {
 			const int og = cw.og, n = cw.n, slot0 = cw.slot0;
+			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
 			if (i == 0 && !(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
 				step0 = 0;
 				last_peak = 0;
 			}
-			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
 			const long long base_step = step0 + (long long)kChunk * i;
-			int k0 = 0;
-			while (true) {
-				const WhbFast snap = w;
-				const bool was_synced = d.synced != 0;
-				uint32_t mask = (ablate & 4) ? (cur.q0.x & 1u) : whb_pass(w, cavg, my_lds, (ablate & 2) ? true : was_synced, k0, nv - 1);
-				if (ablate & 1)
-					mask = 0;
-				int flip_k = -1;
-				while (mask) {
-					const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
-					if (kmin > 31)
-						break;
-					if (kmin > 0)
-						mask &= ~0u << (int)kmin;
-					if (!mask)
-						break;
-					const int k = __builtin_ctz(mask);
-					mask &= mask - 1;
-					const int tdiff = (int)(base_step + k - last_peak);
-					store_bit<2>(d, 0);  // whb.cpp:666-673: one 0, then (bit0 - 1) ones
-					const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
-					for (int q = 1; q < bit0; q++)
-						store_bit<2>(d, 1);
-					last_peak = base_step + k;
-					if (!was_synced && d.synced) {  // the decoder locked at sample k: rssi counts from k on (:677)
-						rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);
-						if (k < nv - 1)
-							flip_k = k;
-						break;
+			bool locked_here = false;
+			// ---- (4) accepted candidates
+			while (mask) {
+				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
+				if (kmin > 31)
+					break;
+				if (kmin > 0)
+					mask &= ~0u << (int)kmin;
+				if (!mask)
+					break;
+				const int k = __builtin_ctz(mask);
+				mask &= mask - 1;
+				const int tdiff = (int)(base_step + k - last_peak);
+				// whb.cpp:666-673: one 0, then (bit0 - 1) ones
+				const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
+				const int len = bit0 > 1 ? bit0 : 1;
+				if (ln == 0 && live) {
+					if (len < kWhbRunEsc) {
+						ent[nent] = (uint16_t)len;
+					} else {
+						ent[nent] = (uint16_t)kWhbRunEsc;
+						ent[nent + 1] = (uint16_t)((uint32_t)len & 0xffff);
+						ent[nent + 2] = (uint16_t)((uint32_t)len >> 16);
 					}
 				}
-				if (flip_k < 0)
-					break;
-				// rewind to the state at k0, redo [k0, flip_k] unsynced to get the state after flip_k, then go on
-				// with (flip_k, nv) in synced mode
-				w = snap;
-				(void)whb_pass(w, cavg, my_lds, false, k0, flip_k);
-				k0 = flip_k + 1;
+				nent += len < kWhbRunEsc ? 1 : 3;
+				// sync search over the run; the registers reach a fixed point after 17 + 32 equal bits, so a very
+				// long run of ones is cut to its first 160 bits
+				bool hit = feed(~1u, len < 32 ? len : 32);
+				for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
+					hit = feed(~0u, rest < 32 ? rest : 32) || hit;
+				last_peak = base_step + k;
+				if (!synced && hit) {  // the decoder locked at sample k: rssi counts from k on (:677)
+					synced = 1;
+					rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);
+					// the average stops after sample k (whb.cpp:653): state and avg_of as of k, and the rest of
+					// the slot's candidates against the frozen avg_of
+					const double yk = yl[k], ykm1 = yl[k > 0 ? k - 1 : 0];
+					const int dk = __shfl(dev, k, 32), dkm1 = __shfl(dev, k > 0 ? k - 1 : 0, 32);
+					f.yn1 = k > 0 ? ykm1 : f.yn;
+					f.yn = yk;
+					f.dn2 = k > 0 ? 0.5 * (double)dkm1 : f.dn1;
+					f.dn1 = 0.5 * (double)dk;
+					avg_of = (int)yk;
+					const unsigned long long b2 = __ballot(ln < nv && ln > k && dev < avg_of && rise);
+					mask = (uint32_t)(b2 >> (32 * grp));
+					locked_here = true;
+				}
 			}
+			if (unsynced0 && !locked_here) {  // the whole slot went through the average
+				const double ye = yl[nv - 1], yem1 = yl[nv > 1 ? nv - 2 : 0];
+				const int dkm1 = __shfl(dev, nv > 1 ? nv - 2 : 0, 32);
+				f.yn1 = nv > 1 ? yem1 : f.yn;
+				f.yn = ye;
+				f.dn2 = nv > 1 ? 0.5 * (double)dkm1 : f.dn1;
+				f.dn1 = 0.5 * (double)__shfl(dev, nv - 1, 32);
+				avg_of = (int)ye;
+			}
+			last_dev = __shfl(dev, nv - 1, 32);
 			if (i == cw.nch - 1) {  // last sample of the window in this submit
-				if (cw.closed) {    // timeout_cnt reached 0, whb.cpp:691-702
-					if (d.synced) {
-						for (int q = 0; q < 16; q++)
-							store_bit<2>(d, 0);
-						const unsigned long long tot = cum_slot_end(slot0, i);
-						flush<2>(e, d, (long long)(rssi_d + (double)(tot - rssi_base)), 0, og + n - 1);
+				WinResult res;
+				res.nbits = nent;
+				res.closed = 0;
+				long long rssi_out = 0;
+				if (cw.closed) {  // timeout_cnt reached 0, whb.cpp:691-702
+					if (synced) {
+						(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
+						rssi_out = (long long)(rssi_d + (double)(cum_slot_end(slot0, i) - rssi_base));
+						res.closed = 1;
+						srr = 0;
+						synced = 0;
 					}
 					rssi_d = 0;
 					rssi_base = 0;
 					step0 = 0;
 					last_peak = 0;
 				} else {  // window continues in the next submit
-					if (d.synced)
+					if (synced)
 						rssi_d += (double)(cum_slot_end(slot0, i) - rssi_base);
 					rssi_base = 0;
 					step0 += n;
 				}
+				res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
+				res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
+				res.lbi_out = 0;
+				res.first_cand_g = -1;
+				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = res.pad_ = 0;
+				if (ln == 0 && live)
+					T.result[(size_t)c * T.cap + j] = res;
+				nent = 0;
 			}
-			cur = nxt;
+			dev_cur = dev_nxt;
 			if (++i >= cw.nch) {
 				j++;
 				i = 0;
@@ -1195,25 +1204,101 @@ __global__ __launch_bounds__(64) void whb_kernel(const uint32_t *__restrict__ de
 			}
 		}
 	}
-	{
+	if (live && ln == 0) {
 		const uint32_t lw = drow[M - 1];
 		st.prev_i = (int)(int16_t)(lw & 0xffff);
 		st.prev_q = (int)lw >> 16;
+		st.timeout_cnt = T.timeout_next[c];
+		st.last_dev = last_dev;
+		st.avg_of = avg_of;
+		st.step = (unsigned long long)step0;
+		st.last_peak = (unsigned long long)last_peak;
+		st.rssi_d = rssi_d;
+		st.iir_avg = f;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ K4'' WHB commit
+// Lane per stream: replays the runs whb_demod_kernel accepted through whb_decoder::store_bit (whb.cpp:566-603)
+// and reports the flushes (whb.cpp:693-697).  ~1 run per 64 in-window samples: cheap, but strictly serial
+// (rdata, byte_cnt and the descrambler carry over from telegram to telegram).
+__global__ __launch_bounds__(64) void whb_commit_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
+							int n_blocks, long long sample_base, ChainLaunch L, int a, WinTables T,
+							tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
+	const int s = blockIdx.x * 64 + threadIdx.x;
+	if (s >= n_streams)
+		return;
+	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
+	const int M = n_blocks * kBlockDec;
+	const ChainParams &p = L.params[a];
+	ChainState &st = L.states[a][s];
+	const int c = a * n_streams + s;
+	const int count = T.count[c];
+	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
+#pragma unroll
+		for (int q = 0; q < 16; q++)
+			dst[q] = src[q];
+	}
+	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
+	       my_rdata };
+	// flat loop: one run per iteration (lanes are at different windows)
+	int j = -1, q = 0, nent = 0, last = 0, widx = -1, flush_it = 0;
+	long long rssi = 0;
+	const uint32_t *ent32 = nullptr;
+	uint32_t wcur = 0, wnext = 0;
+	while (true) {
+		if (q >= nent) {
+			if (flush_it) {  // whb.cpp:693-697
+				for (int z = 0; z < 16; z++)
+					store_bit<2>(d, 0);
+				flush<2>(e, d, rssi, 0, last);
+			}
+			if (++j >= count)
+				break;
+			const int og = T.open[(size_t)c * T.cap + j];
+			const int close = T.close[(size_t)c * T.cap + j];
+			last = close < M ? close : M - 1;
+			const WinResult r = T.result[(size_t)c * T.cap + j];
+			ent32 = T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j;
+			nent = r.nbits;
+			flush_it = r.closed;
+			rssi = (long long)((unsigned long long)(uint32_t)r.rssi_i | ((unsigned long long)(uint32_t)r.offset << 32));
+			q = 0;
+			widx = -1;
+			if (nent > 0)
+				wnext = ent32[0];
+			continue;
+		}
+		const int wi = q >> 1;
+		if (wi != widx) {
+			wcur = wi == widx + 1 ? wnext : ent32[wi];
+			widx = wi;
+			if (2 * (wi + 1) < nent)
+				wnext = ent32[wi + 1];  // in flight while this word's runs are decoded
+		}
+		int len = (q & 1) ? (int)(wcur >> 16) : (int)(wcur & 0xffff);
+		q++;
+		if (len == kWhbRunEsc) {
+			const uint16_t *e16 = reinterpret_cast<const uint16_t *>(ent32);
+			len = (int)((uint32_t)e16[q] | ((uint32_t)e16[q + 1] << 16));
+			q += 2;
+		}
+		store_bit<2>(d, 0);  // whb.cpp:666-673: one 0, then (len - 1) ones
+		for (int m = 1; m < len; m++)
+			store_bit<2>(d, 1);
 	}
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
 		uint4 *dst = reinterpret_cast<uint4 *>(st.rdata);
 #pragma unroll
-		for (int q = 0; q < 16; q++)
-			dst[q] = src[q];
+		for (int q2 = 0; q2 < 16; q2++)
+			dst[q2] = src[q2];
 	}
-	st.timeout_cnt = T.timeout_next[c];
-	st.last_dev = w.last_dev;
-	st.avg_of = w.avg_of;
-	st.step = (unsigned long long)step0;
-	st.last_peak = (unsigned long long)last_peak;
-	st.rssi_d = rssi_d;
-	st.iir_avg = w.iir_avg;
 	st.sr = d.sr;
 	st.sr_cnt = d.sr_cnt;
 	st.byte_cnt = d.byte_cnt;
@@ -1396,8 +1481,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		return e;
 	// Lanes per wave for the serial kernels (tunable for experiments: TFREC_AMD_LANES_*).  Measured on MI355X:
 	// fewer lanes per wave (less lock-step divergence, more waves) is NOT faster -- full waves win.
-	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64),
-			 lanes_whb = env_int("TFREC_AMD_LANES_WHB", 64);
+	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64);
 	dim3 block(64);
 	dim3 grid((n_streams + lanes_chain - 1) / lanes_chain, L.n_active);
 	const int win_blocks = std::min(16384, (int)(((size_t)n_streams * n_blocks * 2 + lanes_win - 1) / lanes_win));
@@ -1406,7 +1490,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
 	mark(1, st);
 	// Two independent kernel chains after the window scan (they touch disjoint state):
-	//   aux stream : WHB   spec_biquad -> fix_biquad -> whb_kernel            (the long pole: starts first)
+	//   aux stream : WHB   spec_biquad -> fix_biquad -> whb_demod_kernel -> whb_commit_kernel
 	//   main stream: TFA   spec_biquad -> fix_biquad -> slicer_kernel -> commit_kernel
 	bool has_whb = false, has_tfa2 = false;
 	for (int a = 0; a < L.n_active; a++) {
@@ -1428,10 +1512,12 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 				   L, T, ld16, dev32, lanes_chain, 2);
 		mark(6, ws);
 		for (int a = 0; a < L.n_active; a++)
-			if (L.params[a].kind == 2)
-				hipLaunchKernelGGL(whb_kernel, dim3((n_streams + lanes_whb - 1) / lanes_whb), block, 0, ws, dec, dec_stride,
-						   dev32, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, lanes_whb,
-						   env_int("TFREC_AMD_ABLATE", 64) & 63);
+			if (L.params[a].kind == 2) {
+				hipLaunchKernelGGL(whb_demod_kernel, dim3((n_streams + 1) / 2), block, 0, ws, dec, dec_stride, dev32,
+						   n_streams, n_blocks, L, a, T);
+				hipLaunchKernelGGL(whb_commit_kernel, dim3((n_streams + 63) / 64), block, 0, ws, dec, dec_stride, n_streams,
+						   n_blocks, sample_base, L, a, T, events, eb, flags);
+			}
 		mark(7, ws);
 		if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
 			return e;
