@@ -222,6 +222,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items())},
                 "gpu_ms_per_step": round(float(np.mean(kt.get("total_ms", [0.0]))), 4),
+                "speculation_stats": r.stats(),
             },
         }
         if a.cpu_budget > 0 and world == 1:

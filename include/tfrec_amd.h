@@ -131,6 +131,17 @@ int tfrec_amd_read_decimated(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_
 /* Samples whose FM-discriminator truncation was closer than 1e-9 to an integer boundary. */
 int tfrec_amd_atan_uncertain(tfrec_amd_ctx *ctx, uint64_t *n);
 int tfrec_amd_get_timings(tfrec_amd_ctx *ctx, tfrec_amd_timings *out);
+/* Cumulative counters of the speculative stages (window-parallel pipeline only).  They only describe how the work
+ * was done -- results do not depend on them. */
+typedef struct {
+	uint64_t biquad_segments;    /* biquad segments processed */
+	uint64_t biquad_unconverged; /* parallel repair runs that reached the end of their segment without joining the
+				        speculative trajectory (normal for a chain's short last segment) */
+	uint64_t biquad_serial;      /* segments the chain walk had to repair serially */
+	uint64_t tfa2_resliced;      /* tfa2 windows sliced again because the last_bit_idx assumption did not hold */
+	uint64_t reserved[4];
+} tfrec_amd_stats;
+int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
 /* Current trigger threshold of one stream (auto mode moves it; fixed mode returns cfg.thresh). */
 int tfrec_amd_read_thresh(tfrec_amd_ctx *ctx, int stream, int *thresh);
 

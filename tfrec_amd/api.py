@@ -49,6 +49,11 @@ class Timings(C.Structure):
                                          "fix_biquad_ms", "slicer_ms", "commit_ms", "whb_ms")]
 
 
+class Stats(C.Structure):
+    _fields_ = [("biquad_segments", C.c_uint64), ("biquad_unconverged", C.c_uint64), ("biquad_serial", C.c_uint64),
+                ("tfa2_resliced", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
 EVENT_DTYPE = np.dtype(
     [
         ("stream", "<u4"),
@@ -69,7 +74,7 @@ EXPORTS = (
     "tfrec_amd_version", "tfrec_amd_strerror", "tfrec_amd_last_error", "tfrec_amd_create", "tfrec_amd_destroy",
     "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
-    "tfrec_amd_get_timings", "tfrec_amd_read_thresh",
+    "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats",
 )
 
 _lib = None
@@ -116,6 +121,7 @@ def load_library(build: bool = True):
     L.tfrec_amd_atan_uncertain.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tfrec_amd_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.tfrec_amd_read_thresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.tfrec_amd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     _lib = L
     return L
 
@@ -217,6 +223,12 @@ class Receiver:
         t = Timings()
         _check(self.L, self.L.tfrec_amd_get_timings(self.h, C.byref(t)))
         return {n: float(getattr(t, n)) for n, _ in Timings._fields_}
+
+    def stats(self) -> dict:
+        """Counters of the speculative stages (how the work was done; results never depend on them)."""
+        st = Stats()
+        _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:4]}
 
 
 def event_tuples(events: np.ndarray, stream: int | None = None):

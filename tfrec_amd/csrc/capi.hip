@@ -53,7 +53,7 @@ struct tfrec_amd_ctx {
 	int16_t *d_fmdev = nullptr;  // [n_streams][m_max] fm_dev of every decimated sample
 	int16_t *d_ld16 = nullptr;   // [chains][m_max] tfa2-family biquad outputs
 	int32_t *d_dev32 = nullptr;  // [n_streams][m_max] WHB stage-1 outputs
-	WinTables win;
+	WinTables win = {};
 	void *win_block = nullptr;
 	FskState *d_fsk = nullptr;  // auto-threshold mode only
 	int wmax = 0;
@@ -313,9 +313,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_count = carve(chains * 4), o_cont = carve(chains * 4), o_tnext = carve(chains * 4);
 		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
 		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve(kNQueues * wins * sizeof(uint2));
-		const size_t o_queue = carve(kNQueues * sizeof(WorkQueue)), o_ovf = carve(4);
-		const size_t o_ckpt = carve(chains * (size_t)T.slots * sizeof(double2)), o_wend = carve(wins * sizeof(BiquadEnd));
-		const size_t o_pw = carve(n * (size_t)T.slots * 8);
+		const size_t o_queue = carve(kNQueues * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(64);
+		T.segcap = (int32_t)((m_max / 32 + (size_t)T.cap) / kSegSlots + 2);
+		const size_t segs = chains * (size_t)T.segcap;
+		const size_t o_ckpt = carve(chains * (size_t)T.slots * sizeof(double2));
+		const size_t o_sstart = carve(segs * sizeof(uint2)), o_vtotal = carve(chains * 4);
+		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
 		ALLOC(c->win_block, off);
 		if (rc == TFREC_AMD_OK) {
 			uint8_t *b = (uint8_t *)c->win_block;
@@ -329,10 +332,15 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.items = (uint2 *)(b + o_items);
 			T.queue = (WorkQueue *)(b + o_queue);
 			T.overflow = (int32_t *)(b + o_ovf);
+			T.stats = (unsigned long long *)(b + o_stats);
 			T.ckpt = (double2 *)(b + o_ckpt);
-			T.wend = (BiquadEnd *)(b + o_wend);
-			T.pw = (unsigned long long *)(b + o_pw);
-			if (hipMemset(T.queue, 0, kNQueues * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess)
+			T.segstart = (uint2 *)(b + o_sstart);
+			T.vtotal = (int32_t *)(b + o_vtotal);
+			T.segend1 = (BiquadEnd *)(b + o_se1);
+			T.segend2 = (BiquadEnd *)(b + o_se2);
+			T.segfix = (int32_t *)(b + o_sfix);
+			if (hipMemset(T.queue, 0, kNQueues * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
+			    hipMemset(T.stats, 0, 64) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
 	}
@@ -566,6 +574,20 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 		if (c->whb_active)
 			HIPCHK(hipEventElapsedTime(&out->whb_ms, c->tev[6], c->tev[7]));
 	}
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_get_stats(tfrec_amd_ctx *c, tfrec_amd_stats *out)
+{
+	if (!c || !out)
+		return TFREC_AMD_E_INVAL;
+	memset(out, 0, sizeof(*out));
+	if (!c->win.stats)
+		return TFREC_AMD_OK;
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipMemcpy(out, c->win.stats, sizeof(*out), hipMemcpyDeviceToHost));
 	return TFREC_AMD_OK;
 }
 

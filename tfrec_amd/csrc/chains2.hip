@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 	const unsigned long long *mrow = mask + (size_t)s * mask_stride;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	// per active slot, wave-uniform
-	int W[kNSlots], t0[kNSlots], open_g[kNSlots], last_trig[kNSlots], count[kNSlots];
+	int W[kNSlots], t0[kNSlots], open_g[kNSlots], last_trig[kNSlots], count[kNSlots], vs[kNSlots];
 	bool open[kNSlots], overflow = false;
 #pragma unroll
 	for (int a = 0; a < kNSlots; a++) {
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 		open_g[a] = 0;
 		last_trig[a] = open[a] ? t0[a] - W[a] : -(1 << 29);  // virtual trigger leaving t0 samples of window
 		count[a] = 0;
+		vs[a] = 0;
 	}
 	// work items are collected per wave in LDS and handed to the global queues with ONE atomic per queue and
 	// flush (thousands of waves pushing single items contend on a handful of counters otherwise)
@@ -216,10 +217,17 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 			const int n = last - og + 1;
 			if (kind < 2)  // slicer work item: queues 2*kind + {0 long, 1 short}
 				push(2 * kind + (n >= kLongWindow ? 0 : 1), make_uint2((uint32_t)c, (uint32_t)count[a]));
-			if (kind > 0) {  // the chain owns a biquad: one speculative item per segment; queue 4: TFA_2 family, 6: WHB
-				const int nseg = (n + kSegSamples - 1) / kSegSamples;
-				for (int sg = 0; sg < nseg; sg++)
-					push(2 + 2 * kind, make_uint2((uint32_t)c | ((uint32_t)sg << 19), (uint32_t)count[a]));
+			if (kind > 0) {  // the chain owns a biquad: an item per segment that starts in this window; queue 4: TFA_2
+				         // family, 6: WHB
+				const int nch = (n + 31) >> 5;
+				const int v0 = vs[a];
+				for (int v = (v0 + kSegSlots - 1) / kSegSlots * kSegSlots; v < v0 + nch; v += kSegSlots) {
+					const int k = v / kSegSlots;
+					if (lane == 0)
+						T.segstart[(size_t)c * T.segcap + k] = make_uint2((uint32_t)count[a], (uint32_t)(v - v0));
+					push(2 + 2 * kind, make_uint2((uint32_t)c, (uint32_t)k));
+				}
+				vs[a] = v0 + nch;
 			}
 		} else
 			overflow = true;
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 				T.count[c] = count[a] < T.cap ? count[a] : T.cap;
 				T.cont[c] = t0[a] > 0 ? 1 : 0;
 				T.timeout_next[c] = tnext;
+				T.vtotal[c] = vs[a];
 			}
 		}
 	}
@@ -334,16 +343,23 @@ struct ChunkIter {
 
 // ------------------------------------------------------------------------------------------------ K3
 // The fp64 biquads (iir2::step) are the one recurrence whose state crosses windows.  They are strongly
-// contracting (pole radius 0.87-0.95): a window started from the WRONG state becomes bit-identical to the true
+// contracting (pole radius 0.87-0.95): a run started from the WRONG state becomes bit-identical to the true
 // trajectory after a few hundred samples, and once the full state (yn, yn1 + the two last inputs) matches
-// bit for bit it matches forever.  So:
-//   K3a spec_biquad_kernel  lane per WINDOW (work queue): runs every window from a zero state (window 0 of a
-//                           chain from the true carried state), stores the truncated outputs the slicers
-//                           consume, a (yn, yn1) checkpoint per 32 samples and the end state;
-//   K3b fix_biquad_kernel   lane per CHAIN: walks the windows in order from the true state, recomputing each
-//                           window's head until its state equals the speculative checkpoint bit for bit --
-//                           from there on the speculative outputs ARE the exact ones.  A window that never
-//                           converges is simply recomputed to its end.  Exactness never depends on convergence.
+// bit for bit it matches forever.  The in-window slots of a chain, numbered consecutively across windows, are
+// cut into segments of kSegSlots slots (>= 3700 samples), and
+//   K3a spec_biquad_kernel   lane per SEGMENT (work queue): runs the segment from a zero state (the chain's
+//                            first segment from the true carried state), stores the truncated outputs the
+//                            slicers consume, a (yn, yn1) checkpoint per slot and the full end state;
+//   K3b repair_biquad_kernel lane per SEGMENT: runs the head of the segment again, now from the END state of
+//                            the previous segment's speculative run, rewriting the outputs until its state
+//                            equals the speculative checkpoint bit for bit -- from there on the stored outputs
+//                            are the continuation of THIS run;
+//   K3c fix_biquad_kernel    lane per CHAIN: walks the segments in order with the true state f.  If f equals the
+//                            state K3b started segment k from (bit for bit), K3b's result for k is the true
+//                            trajectory and f advances by a table look-up; otherwise (the previous segment had
+//                            not converged: practically only a chain's short last segment, which has no
+//                            successor) the segment is repaired serially from f.  Exactness never depends on
+//                            convergence; only speed does.
 // Outputs are window-relative: window j of a chain owns the 32-sample slots (open>>5)+j ... so every chunk is
 // full except a window's tail, and tails may be stored whole.
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load, dword aligned
@@ -393,7 +409,7 @@ __device__ __forceinline__ void k3_load(K3Chunk<WHB> &ch, const void *row, int g
 // Filter `nvalid` samples of a chunk (groups of 8: unpredicated while the whole group is valid).
 template <bool WHB>
 __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const K3Chunk<WHB> &ch, int nvalid,
-					  uint32_t (&ow)[WHB ? 32 : 16], unsigned long long &pw)
+					  uint32_t (&ow)[WHB ? 32 : 16])
 {
 	int pI = (int)(int16_t)(ch.prevw & 0xffff), pQ = (int)ch.prevw >> 16;
 	BiquadT bt = iirt_enter(f, cf);
@@ -407,7 +423,6 @@ __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const
 			if (WHB) {
 				const int I = (int)(int16_t)(ch.w[k] & 0xffff), Q = (int)ch.w[k] >> 16;
 				y = (int)iir_step_t(f, bt, cf, (double)fm_dev_nrzs(I, Q, pI, pQ));  // whb.cpp:651-652
-				pw += (unsigned long long)(uint32_t)(I * I + Q * Q);
 				pI = I;
 				pQ = Q;
 				ow[k] = (uint32_t)y;
@@ -440,95 +455,156 @@ __device__ __forceinline__ void k3_store(void *outrow, int slot, const uint32_t 
 		o[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
 }
 
-template <bool WHB>
-__device__ __forceinline__ void spec_window(int c, int j, int seg, int n_streams, int M, const uint32_t *__restrict__ dec,
-					    size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
-					    const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
-					    int32_t *__restrict__ dev32)
+struct SegWin {
+	int og, n, nch, slot0;
+};
+__device__ __forceinline__ SegWin seg_win(const WinTables &T, int c, int j, int M)
 {
-	const int a = c / n_streams, s = c - a * n_streams;
-	const ChainParams &p = L.params[a];
-	const ChainState &st = L.states[a][s];
-	const int og = T.open[(size_t)c * T.cap + j];
+	SegWin w;
+	w.og = T.open[(size_t)c * T.cap + j];
 	const int close = T.close[(size_t)c * T.cap + j];
-	const int n = (close < M ? close : M - 1) - og + 1;
-	const BiquadCoef cf = p.iir;
+	w.n = (close < M ? close : M - 1) - w.og + 1;
+	w.nch = (w.n + 31) >> 5;
+	w.slot0 = win_slot0(w.og, j);
+	return w;
+}
+
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// Run the biquad over `nslots` consecutive in-window slots of chain c, starting at slot i of window j (the run
+// hops to the following windows as they end).  REPAIR = false: speculative run, stores outputs and checkpoints.
+// REPAIR = true: stores outputs and stops after the first slot (>= min_slots slots, >= 2 samples in) whose end
+// state equals the stored checkpoint bit for bit (the two last inputs are then shared too: from there on the
+// stored trajectory is the continuation of this run).  Returns the slots processed.
+template <bool WHB, bool REPAIR>
+__device__ __forceinline__ int seg_run(Biquad &f, const BiquadCoef &cf, const void *in, void *out, uint32_t prev0,
+				       const WinTables &T, int c, int M, int count, int j, int i, int nslots, int min_slots,
+				       bool &converged)
+{
+	SegWin cw = seg_win(T, c, j, M);
+	SegWin nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
+	double2 *ckrow = T.ckpt + (size_t)c * T.slots;
+	int done = 0, nsamples = 0;
+	converged = false;
+	K3Chunk<WHB> A, B;
+	double2 ckA = make_double2(0, 0), ckB = make_double2(0, 0);
+	k3_load<WHB>(A, in, cw.og + kChunk * i, prev0);
+	if (REPAIR)
+		ckA = ckrow[cw.slot0 + i];
+	// one slot: `cur` is loaded, the slot after it goes to `nxt` while `cur` is filtered; false = stop
+	auto one = [&](const K3Chunk<WHB> &cur, const double2 &ckcur, K3Chunk<WHB> &nxt, double2 &cknxt) -> bool {
+		const bool hop = i + 1 >= cw.nch;
+		const bool more = done + 1 < nslots;
+		const int og2 = hop ? nw.og : cw.og, i2 = hop ? 0 : i + 1, slot2 = (hop ? nw.slot0 : cw.slot0) + i2;
+		if (more) {
+			k3_load<WHB>(nxt, in, og2 + kChunk * i2, prev0);
+			if (REPAIR)
+				cknxt = ckrow[slot2];
+		}
+		uint32_t ow[WHB ? 32 : 16];
+		const int nv = cw.n - kChunk * i < kChunk ? cw.n - kChunk * i : kChunk;
+		k3_filter<WHB>(f, cf, cur, nv, ow);
+		k3_store<WHB>(out, cw.slot0 + i, ow);
+		nsamples += nv;
+		done++;
+		if (!REPAIR) {
+			ckrow[cw.slot0 + i] = make_double2(f.yn, f.yn1);
+		} else if (same_bits(f.yn, ckcur.x) && same_bits(f.yn1, ckcur.y) && nsamples >= 2 && done >= min_slots) {
+			converged = true;
+			return false;
+		}
+		if (!more)
+			return false;
+		if (hop) {
+			j++;
+			cw = nw;
+			nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
+		}
+		i = i2;
+		return true;
+	};
+	while (one(A, ckA, B, ckB) && one(B, ckB, A, ckA)) {
+	}
+	return done;
+}
+
+__device__ __forceinline__ Biquad biquad_of(const BiquadEnd &e)
+{
 	Biquad f;
-	if (j == 0 && seg == 0)
-		f = st.iir;  // the chain's first segment starts from the true carried state
-	else
-		f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;  // speculation: fix_biquad_kernel repairs the head of the segment
+	f.dn1 = e.dn1; f.dn2 = e.dn2; f.yn = e.yn; f.yn1 = e.yn1;
+	return f;
+}
+__device__ __forceinline__ BiquadEnd end_of(const Biquad &f)
+{
+	BiquadEnd e;
+	e.dn1 = f.dn1; e.dn2 = f.dn2; e.yn = f.yn; e.yn1 = f.yn1;
+	return e;
+}
+
+// K3a (repair = 0) and K3b (repair = 1); whb: 0 = TFA_2-family chains, 1 = WHB chains (one kind per launch)
+template <bool WHB>
+__device__ __forceinline__ void seg_task(uint2 it, bool repair, int n_streams, int M, const uint32_t *__restrict__ dec,
+					 size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
+					 const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
+					 int32_t *__restrict__ dev32)
+{
+	const int c = (int)it.x, k = (int)it.y;
+	const int a = c / n_streams, s = c - a * n_streams;
+	const ChainState &st = L.states[a][s];
+	const uint2 start = T.segstart[(size_t)c * T.segcap + k];
+	const int j = (int)start.x, i = (int)start.y;
+	const int left = T.vtotal[c] - k * kSegSlots;
+	const int nslots = left < kSegSlots ? left : kSegSlots;
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
 	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
-	const int slot0 = win_slot0(og, j);
-	const int nchunks = (n + kChunk - 1) >> 5;
-	const int i0 = seg * kSegSlots;
-	const int i1 = nchunks < i0 + kSegSlots ? nchunks : i0 + kSegSlots;
-	unsigned long long pw = 0;  // power prefix, local to the segment
-	K3Chunk<WHB> A, B;
-	k3_load<WHB>(A, in, og + kChunk * i0, prev0);
-	for (int i = i0; i < i1; i += 2) {
-		if (i + 1 < i1)
-			k3_load<WHB>(B, in, og + kChunk * (i + 1), prev0);
-		{
-			uint32_t ow[WHB ? 32 : 16];
-			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
-			k3_filter<WHB>(f, cf, A, nv, ow, pw);
-			k3_store<WHB>(out, slot0 + i, ow);
-			T.ckpt[(size_t)c * T.slots + slot0 + i] = make_double2(f.yn, f.yn1);
-			if (WHB)
-				T.pw[(size_t)s * T.slots + slot0 + i] = pw;
+	const size_t sk = (size_t)c * T.segcap + k;
+	bool conv;
+	Biquad f;
+	if (!repair) {
+		if (k == 0)
+			f = st.iir;  // the chain's first segment starts from the true carried state
+		else
+			f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
+		(void)seg_run<WHB, false>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
+		T.segend1[sk] = end_of(f);
+	} else if (k > 0) {
+		f = biquad_of(T.segend1[sk - 1]);
+		const int done = seg_run<WHB, true>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
+		T.segfix[sk] = done | (conv ? kSegConverged : 0);
+		if (!conv) {
+			T.segend2[sk] = end_of(f);
+			atomicAdd(&T.stats[1], 1ull);
 		}
-		if (i + 1 >= i1)
-			break;
-		if (i + 2 < i1)
-			k3_load<WHB>(A, in, og + kChunk * (i + 2), prev0);
-		{
-			uint32_t ow[WHB ? 32 : 16];
-			const int nv = n - kChunk * (i + 1) < kChunk ? n - kChunk * (i + 1) : kChunk;
-			k3_filter<WHB>(f, cf, B, nv, ow, pw);
-			k3_store<WHB>(out, slot0 + i + 1, ow);
-			T.ckpt[(size_t)c * T.slots + slot0 + i + 1] = make_double2(f.yn, f.yn1);
-			if (WHB)
-				T.pw[(size_t)s * T.slots + slot0 + i + 1] = pw;
-		}
-	}
-	if (i1 == nchunks) {  // the window's last segment: its end state in full
-		BiquadEnd &we = T.wend[(size_t)c * T.cap + j];
-		we.dn1 = f.dn1;
-		we.dn2 = f.dn2;
-		we.yn = f.yn;
-		we.yn1 = f.yn1;
 	}
 }
 
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							 int32_t *__restrict__ dev32, int lanes, int whb)
+							 int32_t *__restrict__ dev32, int lanes, int whb, int repair)
 {
 	if ((int)threadIdx.x >= lanes)
 		return;
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-	// whb: 0 = TFA_2-family windows, 1 = WHB windows (a launch runs one kind of biquad window)
-	for (int q = 4 + 2 * whb; q < 6 + 2 * whb; q++) {
-		const uint32_t count = T.queue[q].count;
-		while (true) {
-			const uint32_t idx = atomicAdd(&T.queue[q].head, 1u);
-			if (idx >= count)
-				break;
-			const uint2 it = T.items[(size_t)q * total + idx];
-			const int c = (int)(it.x & 0x7ffffu), seg = (int)(it.x >> 19), j = (int)it.y;
-			if (whb)
-				spec_window<true>(c, j, seg, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
-			else
-				spec_window<false>(c, j, seg, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
-		}
+	const int q = 4 + 2 * whb;
+	const uint32_t count = T.queue[q].count;
+	uint32_t *head = repair ? &T.queue[q + 1].head : &T.queue[q].head;
+	while (true) {
+		const uint32_t idx = atomicAdd(head, 1u);
+		if (idx >= count)
+			break;
+		const uint2 it = T.items[(size_t)q * total + idx];
+		if (whb)
+			seg_task<true>(it, repair != 0, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+		else
+			seg_task<false>(it, repair != 0, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 	}
 }
 
+// K3c: see the K3 header.  A flat loop -- per iteration a lane either checks one segment (table look-ups) or
+// repairs one slot -- so that the lanes of a wave (different chains) never wait for each other's repairs.
 template <bool WHB>
 __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, const uint32_t *__restrict__ dec,
 					  size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
@@ -536,96 +612,89 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 					  int32_t *__restrict__ dev32)
 {
 	const int c = a * n_streams + s;
-	const ChainParams &p = L.params[a];
 	ChainState &st = L.states[a][s];
-	const int count = T.count[c];
-	if (count == 0)
+	const int vtotal = T.vtotal[c];
+	if (vtotal == 0)
 		return;
-	const BiquadCoef cf = p.iir;
+	const int nseg = (vtotal + kSegSlots - 1) / kSegSlots;
+	atomicAdd(&T.stats[0], (unsigned long long)nseg);
+	const int count = T.count[c];
+	const BiquadCoef cf = L.params[a].iir;
+	const BiquadEnd *e1 = T.segend1 + (size_t)c * T.segcap;
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
 	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
-	// biquad input of sample g (to rebuild dn1/dn2 at the end of a segment)
-	auto input_at = [&](int g) -> double {
-		if (WHB) {
-			const uint32_t *drow = static_cast<const uint32_t *>(in);
-			const uint32_t cw = drow[g], pw = g > 0 ? drow[g - 1] : prev0;
-			return (double)fm_dev_nrzs((int)(int16_t)(cw & 0xffff), (int)cw >> 16, (int)(int16_t)(pw & 0xffff), (int)pw >> 16);
-		}
-		return (double)static_cast<const int16_t *>(in)[g];
-	};
-	Biquad f;  // the TRUE filter state while walking the chain
-	f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
-	// state at the end of segment (j, seg) of the stored trajectory (exact once the segment is exact / converged)
-	auto seg_end = [&](int og, int slot0, int j, int seg, bool last_seg) -> Biquad {
-		Biquad r;
-		if (last_seg) {
-			const BiquadEnd e = T.wend[(size_t)c * T.cap + j];
-			r.dn1 = e.dn1; r.dn2 = e.dn2; r.yn = e.yn; r.yn1 = e.yn1;
-		} else {  // a full segment of kSegSamples (>= 2) samples
-			const int r_end = (seg + 1) * kSegSamples - 1;
-			const double2 ck = T.ckpt[(size_t)c * T.slots + slot0 + (r_end >> 5)];
-			r.yn = ck.x; r.yn1 = ck.y;
-			r.dn1 = input_at(og + r_end);
-			r.dn2 = input_at(og + r_end - 1);
-		}
-		return r;
-	};
-	// flat loop over (window, segment, chunk); the chunk after the current one is always in flight
-	int j = -1, seg = 0, nseg = 0, i = 0, iend = 0, og = 0, n = 0, slot0 = 0, nchunks = 0;
-	bool fixing = false, last_seg = false;
+	const double2 *ckrow = T.ckpt + (size_t)c * T.slots;
+	BiquadEnd prev = e1[0], cur = prev;
+	Biquad f = biquad_of(prev);  // the TRUE state after segment 0
+	int k = 1;
+	bool repairing = false;
+	// repair state
+	int j = 0, i = 0, nslots = 0, min_slots = 0, done = 0, nsamples = 0;
+	SegWin cw = { 0, 0, 0, 0 }, nw = cw;
 	K3Chunk<WHB> A, B;
-	double2 ckA = make_double2(0, 0), ckB = make_double2(0, 0);
+	double2 ckA = make_double2(0, 0), ckB = ckA;
 	while (true) {
-		if (!fixing) {
-			if (++seg >= nseg) {
-				if (++j >= count)
-					break;
-				og = T.open[(size_t)c * T.cap + j];
-				const int close = T.close[(size_t)c * T.cap + j];
-				n = (close < M ? close : M - 1) - og + 1;
-				nchunks = (n + kChunk - 1) >> 5;
-				slot0 = win_slot0(og, j);
-				nseg = (n + kSegSamples - 1) / kSegSamples;
-				seg = 0;
-			}
-			last_seg = seg == nseg - 1;
-			if (j == 0 && seg == 0) {  // ran from the true carried state: already exact
-				f = seg_end(og, slot0, j, seg, last_seg);
+		if (!repairing) {
+			if (k >= nseg)
+				break;
+			cur = e1[k];
+			const int fx = T.segfix[(size_t)c * T.segcap + k];
+			if (same_bits(f.yn, prev.yn) && same_bits(f.yn1, prev.yn1) && same_bits(f.dn1, prev.dn1) &&
+			    same_bits(f.dn2, prev.dn2)) {
+				// K3b ran segment k from the true state: what is stored now is the true trajectory
+				f = biquad_of((fx & kSegConverged) ? cur : T.segend2[(size_t)c * T.segcap + k]);
+				prev = cur;
+				k++;
 				continue;
 			}
-			i = seg * kSegSlots;
-			iend = nchunks < i + kSegSlots ? nchunks : i + kSegSlots;
-			k3_load<WHB>(A, in, og + kChunk * i, prev0);
-			ckA = T.ckpt[(size_t)c * T.slots + slot0 + i];
-			fixing = true;
+			// K3b started from a wrong state: repair serially from f, at least as far as K3b had written
+			atomicAdd(&T.stats[2], 1ull);
+			const uint2 start = T.segstart[(size_t)c * T.segcap + k];
+			j = (int)start.x;
+			i = (int)start.y;
+			const int left = vtotal - k * kSegSlots;
+			nslots = left < kSegSlots ? left : kSegSlots;
+			min_slots = fx & ~kSegConverged;
+			done = 0;
+			nsamples = 0;
+			cw = seg_win(T, c, j, M);
+			nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
+			k3_load<WHB>(A, in, cw.og + kChunk * i, prev0);
+			ckA = ckrow[cw.slot0 + i];
+			repairing = true;
 		}
-		const int inext = i + 1 < iend ? i + 1 : i;
-		k3_load<WHB>(B, in, og + kChunk * inext, prev0);
-		ckB = T.ckpt[(size_t)c * T.slots + slot0 + inext];
+		// one slot of the repair run (cf. seg_run<.., true>)
+		const bool hop = i + 1 >= cw.nch;
+		const bool more = done + 1 < nslots;
+		const int og2 = hop ? nw.og : cw.og, i2 = hop ? 0 : i + 1, slot2 = (hop ? nw.slot0 : cw.slot0) + i2;
+		if (more) {
+			k3_load<WHB>(B, in, og2 + kChunk * i2, prev0);
+			ckB = ckrow[slot2];
+		}
 		uint32_t ow[WHB ? 32 : 16];
-		unsigned long long pw_unused = 0;
-		const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
-		k3_filter<WHB>(f, cf, A, nv, ow, pw_unused);
-		k3_store<WHB>(out, slot0 + i, ow);
-		// bit-for-bit state match with the speculative run?  (the two last inputs are shared once 2 samples in)
-		const bool same = __double_as_longlong(f.yn) == __double_as_longlong(ckA.x) &&
-				  __double_as_longlong(f.yn1) == __double_as_longlong(ckA.y) &&
-				  (kChunk * (i - seg * kSegSlots) + nv) >= 2;
-		if (same) {
-			f = seg_end(og, slot0, j, seg, last_seg);  // the rest of the segment's speculative run is exact
-			fixing = false;
-		} else if (++i >= iend) {  // the segment ended without convergence: f IS its true end state
-			if (last_seg) {
-				BiquadEnd e;
-				e.dn1 = f.dn1; e.dn2 = f.dn2; e.yn = f.yn; e.yn1 = f.yn1;
-				T.wend[(size_t)c * T.cap + j] = e;
-			}
-			fixing = false;
-		} else {
-			A = B;
-			ckA = ckB;
+		const int nv = cw.n - kChunk * i < kChunk ? cw.n - kChunk * i : kChunk;
+		k3_filter<WHB>(f, cf, A, nv, ow);
+		k3_store<WHB>(out, cw.slot0 + i, ow);
+		nsamples += nv;
+		done++;
+		const bool joined = same_bits(f.yn, ckA.x) && same_bits(f.yn1, ckA.y) && nsamples >= 2 && done >= min_slots;
+		if (joined || !more) {
+			if (joined)
+				f = biquad_of(cur);  // joined the speculative trajectory: its end state is the true one
+			prev = cur;
+			k++;
+			repairing = false;
+			continue;
 		}
+		if (hop) {
+			j++;
+			cw = nw;
+			nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
+		}
+		i = i2;
+		A = B;
+		ckA = ckB;
 	}
 	st.iir = f;
 }
@@ -981,7 +1050,6 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	const int M = n_blocks * kBlockDec;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	const int32_t *dvrow = dev32 + (size_t)s * T.slots * 32;
-	const unsigned long long *pwrow = T.pw + (size_t)s * T.slots;
 	const BiquadCoef cavg = p.iir_avg;
 	const double spb = p.spb;
 	const double thr = 3 * spb / 4;        // whb.cpp:664
@@ -994,8 +1062,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	Biquad f = st.iir_avg;
 	int avg_of = st.avg_of, last_dev = st.last_dev;
 	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
+	// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
+	// additions are exact in any order: the lanes add their samples' power in integers.
 	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
-	unsigned long long rssi_base = 0;      // power prefix just before the first synced sample (this submit)
+	unsigned long long rssi_acc = 0;       // ... and in this submit
 	int synced = st.synced;
 	// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
 	// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
@@ -1005,24 +1075,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	const int count = live ? T.count[c] : 0;
 	const bool cont = T.cont[c] != 0;
 
-	// K3a stores the power prefix per slot, restarting at every kSegSlots-slot segment of a window:
-	// window-cumulative power up to the END of window-relative slot ci (this submit)
-	auto cum_slot_end = [&](int slot0, int ci) -> unsigned long long {
-		unsigned long long v = pwrow[slot0 + ci];
-		for (int sg = 0; sg < ci / kSegSlots; sg++)
-			v += pwrow[slot0 + kSegSlots * (sg + 1) - 1];
-		return v;
-	};
-	// ... and up to and including window-relative sample r
-	auto prefix_at = [&](int og, int slot0, int r) -> unsigned long long {
-		if (r < 0)
-			return 0ull;
-		unsigned long long v = (r >> 5) > 0 ? cum_slot_end(slot0, (r >> 5) - 1) : 0ull;
-		for (int q = r & ~31; q <= r; q++) {
-			const uint32_t cw = drow[og + q];
-			const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
-			v += (unsigned long long)(uint32_t)(I * I + Q * Q);
-		}
+	// sum over the 32 lanes of the stream
+	auto group_sum = [&](unsigned long long v) -> unsigned long long {
+#pragma unroll
+		for (int o = 16; o >= 1; o >>= 1)
+			v += __shfl_xor(v, o, 32);
 		return v;
 	};
 	// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
@@ -1064,6 +1121,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		const int ns = (i + 1 < cw.nch) ? cw.slot0 + i + 1 : (j + 1 < count ? nw.slot0 : cw.slot0 + i);
 		const int dev_nxt = act ? dvrow[(size_t)ns * 32 + ln] : 0;
 		const int dev = dev_cur;
+		const uint32_t iqw = act ? drow[cw.og + kChunk * i + ln] : 0u;  // the lane's decimated sample (for the rssi)
 		const int devm1 = __shfl_up(dev, 1, 32), devm2 = __shfl_up(dev, 2, 32);
 		const bool rise = dev > (ln >= 1 ? devm1 : last_dev);  // dev > last_dev, whb.cpp:663
 		const bool unsynced0 = act && !synced;
@@ -1095,15 +1153,17 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		const unsigned long long bal = __ballot(act && ln < nv && dev < avgn && rise);
 		uint32_t mask = (uint32_t)(bal >> (32 * grp));
 		if (act) {
-			const int og = cw.og, n = cw.n, slot0 = cw.slot0;
+			const int og = cw.og, n = cw.n;
 			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
 			if (i == 0 && !(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
+				rssi_acc = 0;
 				step0 = 0;
 				last_peak = 0;
 			}
 			const long long base_step = step0 + (long long)kChunk * i;
 			bool locked_here = false;
+			int rssi_from = synced ? 0 : kChunk;  // first sample of the slot that counts for the rssi
 			// ---- (4) accepted candidates
 			while (mask) {
 				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
@@ -1137,7 +1197,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				last_peak = base_step + k;
 				if (!synced && hit) {  // the decoder locked at sample k: rssi counts from k on (:677)
 					synced = 1;
-					rssi_base = prefix_at(og, slot0, kChunk * i + k - 1);
+					rssi_from = k;
 					// the average stops after sample k (whb.cpp:653): state and avg_of as of k, and the rest of
 					// the slot's candidates against the frozen avg_of
 					const double yk = yl[k], ykm1 = yl[k > 0 ? k - 1 : 0];
@@ -1162,6 +1222,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				avg_of = (int)ye;
 			}
 			last_dev = __shfl(dev, nv - 1, 32);
+			if (rssi_from < nv) {  // whb.cpp:677-678
+				const int I = (int)(int16_t)(iqw & 0xffff), Q = (int)iqw >> 16;
+				rssi_acc += group_sum(ln >= rssi_from && ln < nv ? (unsigned long long)(uint32_t)(I * I + Q * Q) : 0ull);
+			}
 			if (i == cw.nch - 1) {  // last sample of the window in this submit
 				WinResult res;
 				res.nbits = nent;
@@ -1170,19 +1234,18 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				if (cw.closed) {  // timeout_cnt reached 0, whb.cpp:691-702
 					if (synced) {
 						(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
-						rssi_out = (long long)(rssi_d + (double)(cum_slot_end(slot0, i) - rssi_base));
+						rssi_out = (long long)(rssi_d + (double)rssi_acc);
 						res.closed = 1;
 						srr = 0;
 						synced = 0;
 					}
 					rssi_d = 0;
-					rssi_base = 0;
+					rssi_acc = 0;
 					step0 = 0;
 					last_peak = 0;
 				} else {  // window continues in the next submit
-					if (synced)
-						rssi_d += (double)(cum_slot_end(slot0, i) - rssi_base);
-					rssi_base = 0;
+					rssi_d += (double)rssi_acc;
+					rssi_acc = 0;
 					step0 += n;
 				}
 				res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
@@ -1366,9 +1429,11 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 						// the speculative run saw: glitch test passed, edge counted, nothing emitted, last_bit kept
 						// (tfa2.cpp:391-409 with a huge tdiff).  The true run does the same iff:
 						const bool same = (index_c > lbi_c + 8) && !(tdiff > p.spb / 4 && tdiff < 32 * p.spb);
-						if (!same)
+						if (!same) {
+							atomicAdd(&T.stats[3], 1ull);
 							window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
 								       rebase_lbi(lbi, lbi_block, og >> 13), my_lds);
+						}
 						lbi = rr->lbi_out;
 					} else {
 						lbi = rebase_lbi(lbi, lbi_block, last >> 13);  // no candidate edge: it just ages
@@ -1485,6 +1550,9 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	dim3 block(64);
 	dim3 grid((n_streams + lanes_chain - 1) / lanes_chain, L.n_active);
 	const int win_blocks = std::min(16384, (int)(((size_t)n_streams * n_blocks * 2 + lanes_win - 1) / lanes_win));
+	// biquad segments: at most (M/32 + windows)/kSegSlots + 1 per chain
+	const int seg_blocks = std::min(16384, (int)(((size_t)L.n_active * n_streams * ((size_t)n_blocks * (kBlockDec / 32) / kSegSlots + 4) +
+						       lanes_win - 1) / lanes_win));
 	(void)slicer_waves;
 	mark(0, st);
 	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
@@ -1506,8 +1574,10 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			forked = true;
 			ws = aux;
 		}
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 1);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 0);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 1);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 2);
 		mark(6, ws);
@@ -1523,8 +1593,10 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			return e;
 	}
 	if (has_tfa2) {
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(win_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
 		mark(2, st);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 1);

@@ -125,19 +125,27 @@ struct WinTables {
 	int32_t *close;         // [chains*cap] sample at which the window's flush fires (>= M: after this submit)
 	WinResult *result;      // [chains*cap]
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
-	uint2 *items;           // [8][chains*cap] work items (chain, j); slicer queues 2*kind + {0: long, 1: short windows},
-	                        // queues 4,5 (TFA_2 family) and 6,7 (WHB): windows of chains that own a biquad (long, short)
+	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
+	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment).  The heads of
+	                        // queues 5 / 7 serve the repair pass over the same items.
 	WorkQueue *queue;       // [8]
 	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
 	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
-	BiquadEnd *wend;        // [chains*cap] biquad state after the window's last sample of this submit
-	unsigned long long *pw; // [n_streams*slots] WHB: sum of I^2+Q^2 from the window's first sample to the slot's end
+	// biquad segments: the in-window slots of a chain, numbered consecutively across windows ("virtual slots"),
+	// are cut into segments of kSegSlots slots
+	int32_t segcap;         // segments per chain the tables can hold
+	uint2 *segstart;        // [chains*segcap] (window j, window-relative slot) where the segment starts
+	int32_t *vtotal;        // [chains] virtual slots of the chain in this submit
+	BiquadEnd *segend1;     // [chains*segcap] state after the segment, speculative run
+	BiquadEnd *segend2;     // [chains*segcap] state after the segment, repair run that did not converge
+	int32_t *segfix;        // [chains*segcap] repair run: slots rewritten | kSegConverged
 	int32_t *overflow;      // set when a chain found more than cap windows
+	unsigned long long *stats;  // [8] tfrec_amd_stats
 };
 
 constexpr int kNQueues = 8;
-constexpr int kSegSlots = 128;                   // speculative biquad segments: 128 slots = 4096 samples
-constexpr int kSegSamples = kSegSlots * 32;
+constexpr int kSegSlots = 128;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
+constexpr int kSegConverged = 0x40000000;
 constexpr int kLongWindow = 6000;  // samples; longer windows are handed out first (tail balance)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
