@@ -153,7 +153,7 @@ hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stri
 // A gap that closes a window is >= W-1 >= 355 samples, so it always spans whole 64-bit words: only the first
 // trigger of a run's first word and the last trigger of its last word matter.
 __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *__restrict__ mask, size_t mask_stride,
-						     int n_streams, int n_blocks, ChainLaunch L, WinTables T)
+						     int n_streams, int n_blocks, ChainLaunch L, WinTables T, int long_window)
 {
 	const int s = blockIdx.x;
 	const int lane = threadIdx.x;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 			const int last = close < M ? close : M - 1;
 			const int n = last - og + 1;
 			if (kind < 2)  // slicer work item: queues 2*kind + {0 long, 1 short}
-				push(2 * kind + (n >= kLongWindow ? 0 : 1), make_uint2((uint32_t)c, (uint32_t)count[a]));
+				push(2 * kind + (n >= long_window ? 0 : 1), make_uint2((uint32_t)c, (uint32_t)count[a]));
 			if (kind > 0) {  // the chain owns a biquad: an item per segment that starts in this window; queue 4: TFA_2
 				         // family, 6: WHB
 				const int nch = (n + 31) >> 5;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int q = 4 + 2 * whb;
 	const uint32_t count = T.queue[q].count;
-	uint32_t *head = repair ? &T.queue[q + 1].head : &T.queue[q].head;
+	uint32_t *head = repair ? &T.queue[q].head2 : &T.queue[q].head;
 	while (true) {
 		const uint32_t idx = atomicAdd(head, 1u);
 		if (idx >= count)
@@ -830,10 +830,12 @@ struct Slot4 {
 // Run one window [g0, last] of a TFA_1 (KIND 0) or TFA_2-family (KIND 1) slicer.  Each 32-sample chunk is moved
 // from registers to the lane's LDS column, the next chunk's loads are issued, then the chunk is walked from
 // LDS by a rolled loop (small code, HBM latency overlapped with the state machine).
+// handoff (TFA_2 family, long windows): stop after the chunk in which bitcnt reached 10 -- from there on the
+// thresholds are frozen and the wave-cooperative slicer takes over.  Returns the first chunk NOT done (nch: all).
 template <int KIND>
-__device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int last, bool closed,
-					   const uint32_t *__restrict__ drow, const uint32_t *__restrict__ ldslots, int prevI,
-					   int prevQ, double spb, uint4 *__restrict__ my_lds)
+__device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int last, bool closed,
+					  const uint32_t *__restrict__ drow, const uint32_t *__restrict__ ldslots, int prevI,
+					  int prevQ, double spb, uint4 *__restrict__ my_lds, bool handoff)
 {
 	const int n = last - g0 + 1;
 	const int nch = (n + kChunk - 1) >> 5;
@@ -911,6 +913,8 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 			}
 			bw.chunk_end();
 			cur = nxt;
+			if (handoff && f.bitcnt >= 10 && i + 1 < nch)
+				return i + 1;
 		}
 	}
 	const int bl = last >> 13;
@@ -921,12 +925,14 @@ __device__ __forceinline__ void run_window(Slicer &f, BitWriter &bw, int g0, int
 	if (closed && KIND == 1)  // tfa2.cpp:430-431: trailing bits before the flush
 		for (int q = 0; q < 16; q++)
 			bw.put(f.last_bit);
+	return nch;
 }
 
 template <int KIND>
 __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					    size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
-					    const WinTables &T, bool exact_lbi, int lbi_in_override, uint4 *__restrict__ my_lds)
+					    const WinTables &T, bool exact_lbi, int lbi_in_override, uint4 *__restrict__ my_lds,
+					    bool handoff)
 {
 	const int a = c / n_streams, s = c - a * n_streams;
 	const ChainParams &p = L.params[a];
@@ -962,9 +968,10 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
 							(size_t)win_slot0(og, j) * 16
 					      : nullptr;
-	run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, my_lds);
+	const int resume = run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, my_lds, handoff);
 	bw.finish();
 	WinResult &r = T.result[(size_t)c * T.cap + j];
+	r.resume = resume < ((last - og + 1 + kChunk - 1) >> 5) ? resume : -1;
 	r.nbits = bw.n;
 	r.closed = closed ? 1 : 0;
 	r.rssi_i = f.rssi_i;
@@ -979,8 +986,10 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-// Persistent lanes pull (chain, window) items, long windows first.  blockIdx.y = protocol kind (0 TFA_1,
-// 1 TFA_2 family), each with its own pair of queues, so a wave runs one slicer type.
+// Persistent lanes pull (chain, window) items.  blockIdx.y = protocol kind (0 TFA_1, 1 TFA_2 family), each with
+// its own pair of queues, so a wave runs one slicer type.  Short windows are sliced completely; of the long
+// TFA_2-family windows only the head (until the thresholds freeze, tfa2.cpp:363 "bitcnt < 10") -- the rest,
+// and the long TFA_1 windows, belong to coop_slicer_kernel.
 __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks, ChainLaunch L,
 						    WinTables T, int lanes)
@@ -992,8 +1001,9 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int kind = blockIdx.y;
-	for (int q = 2 * kind; q < 2 * kind + 2; q++) {
+	for (int q = 2 * kind + (kind == 0 ? 1 : 0); q < 2 * kind + 2; q++) {
 		const uint32_t count = T.queue[q].count;
+		const bool handoff = (q & 1) == 0;
 		while (true) {
 			const uint32_t idx = atomicAdd(&T.queue[q].head, 1u);
 			if (idx >= count)
@@ -1001,10 +1011,277 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 			const uint2 it = T.items[(size_t)q * total + idx];
 			const int c = (int)it.x, j = (int)it.y;
 			if (kind == 0)
-				window_task<0>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds);
+				window_task<0>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds, false);
 			else
-				window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds);
+				window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds, handoff);
 		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ K4b
+// Wave-cooperative slicers for LONG windows: one wave per window, lane n owns sample n of a 64-sample step.
+// A lane-per-window slicer needs ~100 instructions per sample on a serial path; a 40 000-sample burst then
+// takes milliseconds whatever the GPU's width.  Here the per-sample work is done by 64 lanes at once and only
+// the sparse part stays serial (wave-uniform):
+//   TFA_2 family (tfa2.cpp:357-412, after the thresholds froze): the candidate edges are two ballots
+//       (ld > hi, ld < lo); the walk visits only the candidates of the polarity that can flip last_bit.
+//   TFA_1 (tfa1.cpp:150-178): the peak detector mark_lvl = dev > mark_lvl ? dev : (int)(mark_lvl*0.95) is a
+//       64-step uniform recurrence (6 instructions per sample); "dev < mark_lvl/2" is a ballot, and the walk
+//       handles each RUN of consecutive candidates in O(1): only the first sample of a run can emit bits (later
+//       gaps are <= 4), the others move last_bit_idx forward by 4 every second sample.
+// Bits are appended by a wave-uniform writer (lane 0 stores).
+struct CoopBits {
+	uint32_t *base;
+	unsigned long long acc;
+	int nacc;  // valid bits in acc
+	int n;     // bits written so far, including acc
+	__device__ __forceinline__ void init(uint32_t *b, int nbits)
+	{
+		base = b;
+		n = nbits;
+		nacc = nbits & 31;
+		acc = nacc ? (unsigned long long)(b[nbits >> 5] & ((1u << nacc) - 1u)) : 0ull;
+	}
+	__device__ __forceinline__ void put_run(int bit, int cnt)
+	{
+		while (cnt > 0) {
+			const int take = cnt < 32 ? cnt : 32;
+			if (bit)
+				acc |= ((1ull << take) - 1ull) << nacc;
+			nacc += take;
+			n += take;
+			cnt -= take;
+			if (nacc >= 32) {
+				if (threadIdx.x == 0)
+					base[(n - nacc) >> 5] = (uint32_t)acc;
+				acc >>= 32;
+				nacc -= 32;
+			}
+		}
+	}
+	__device__ __forceinline__ void finish()
+	{
+		if (nacc && threadIdx.x == 0)
+			base[(n - nacc) >> 5] = (uint32_t)acc;
+	}
+};
+
+__device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, const int16_t *__restrict__ ld16,
+					  const ChainLaunch &L, const WinTables &T)
+{
+	const int lane = threadIdx.x;
+	const int a = c / n_streams;
+	const double spb = L.params[a].spb;
+	WinResult &rr = T.result[(size_t)c * T.cap + j];
+	const WinResult r0 = rr;
+	if (r0.resume < 0)
+		return;  // the lane-per-window pass finished the window
+	const int og = T.open[(size_t)c * T.cap + j];
+	const int close = T.close[(size_t)c * T.cap + j];
+	const bool closed = close < M;
+	const int last = closed ? close : M - 1;
+	const int g1 = og + kChunk * r0.resume;  // first sample still to do
+	const int16_t *ldrow = ld16 + (size_t)c * T.slots * 32 + (size_t)win_slot0(og, j) * 32;  // window-relative
+	// frozen thresholds (tfa2.cpp:379-381)
+	const int noffset = d2i(0.9 * r0.offset);
+	const int hi = noffset + r0.dmax / 32, lo = noffset + r0.dmin / 32;
+	int last_bit = r0.last_bit, bitcnt = r0.bitcnt, first_cand_g = r0.first_cand_g;
+	int cur_block = (g1 - 1) >> 13;
+	int lbi = r0.lbi_out;  // relative to cur_block (run_window leaves it relative to the block of its last sample)
+	CoopBits bw;
+	bw.init(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, r0.nbits);
+	int ld_nxt = g1 + lane <= last ? (int)ldrow[g1 - og + lane] : 0;
+	for (int gb = g1; gb <= last; gb += 64) {
+		const int ld = ld_nxt;
+		if (gb + 64 <= last)
+			ld_nxt = gb + 64 + lane <= last ? (int)ldrow[gb + 64 - og + lane] : 0;
+		const bool valid = gb + lane <= last;
+		const unsigned long long m1 = __ballot(valid && ld > hi);
+		const unsigned long long m0 = __ballot(valid && ld < lo) & ~m1;
+		unsigned long long todo = ~0ull;  // positions not yet visited
+		while (true) {
+			const unsigned long long m = (last_bit ? m0 : m1) & todo;
+			if (!m)
+				break;
+			const int k = __builtin_ctzll(m);
+			todo = k >= 63 ? 0ull : (~0ull << (k + 1));
+			const int g = gb + k;
+			const int b = g >> 13;
+			if (b != cur_block) {
+				lbi = rebase_lbi(lbi, cur_block, b);
+				cur_block = b;
+			}
+			const int index = 2 * (g & (kBlockDec - 1));
+			const int bit = last_bit ^ 1;
+			if (first_cand_g < 0)
+				first_cand_g = g;
+			if (index > lbi + 8) {  // tfa2.cpp:391-406
+				bitcnt++;
+				const int tdiff = index - lbi;
+				if (tdiff > spb / 4 && tdiff < 32 * spb) {
+					const int numbits = d2i(((tdiff / 2) + (spb / 2)) / spb);
+					if (numbits < 32)
+						bw.put_run(last_bit, numbits - 1);
+					bw.put_run(bit, 1);
+					last_bit = bit;
+				}
+			}
+			if (index - lbi > 2)
+				lbi = index;
+		}
+	}
+	const int bl = last >> 13;
+	if (bl != cur_block) {
+		lbi = rebase_lbi(lbi, cur_block, bl);
+		cur_block = bl;
+	}
+	if (closed)  // tfa2.cpp:430-431: trailing bits before the flush
+		bw.put_run(last_bit, 16);
+	bw.finish();
+	if (lane == 0) {
+		WinResult r = r0;
+		r.nbits = bw.n;
+		r.lbi_out = lbi;
+		r.first_cand_g = first_cand_g;
+		r.bitcnt = bitcnt;
+		r.last_bit = last_bit;
+		r.resume = -1;
+		rr = r;
+	}
+}
+
+__device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
+					  size_t dec_stride, const ChainLaunch &L, const WinTables &T, int *__restrict__ lds_m)
+{
+	const int lane = threadIdx.x;
+	const int a = c / n_streams, s = c - a * n_streams;
+	const ChainState &st = L.states[a][s];
+	const int og = T.open[(size_t)c * T.cap + j];
+	const int close = T.close[(size_t)c * T.cap + j];
+	const bool closed = close < M;
+	const int last = closed ? close : M - 1;
+	const bool cont = (j == 0) && T.cont[c];
+	const uint32_t *drow = dec + (size_t)s * dec_stride;
+	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
+	int mark = 0, lbi = 0;  // tfa1.cpp:183: the window opens with last_bit_idx = 0
+	int cur_block = og >> 13;
+	int rssi_lane = 0;
+	if (cont) {  // resume the window the previous submit left open
+		mark = st.mark_lvl;
+		rssi_lane = st.rssi_i;
+		lbi = rebase_lbi(st.last_bit_idx, -1, cur_block);
+	}
+	CoopBits bw;
+	bw.init(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0);
+	auto load = [&](int g) -> uint2 {  // (sample, previous sample)
+		uint2 v;
+		v.x = drow[g];
+		v.y = g > 0 ? drow[g - 1] : prev0;
+		return v;
+	};
+	uint2 nxt = load(og + lane <= last ? og + lane : last);
+	for (int gb = og; gb <= last; gb += 64) {
+		const uint2 cur = nxt;
+		if (gb + 64 <= last)
+			nxt = load(gb + 64 + lane <= last ? gb + 64 + lane : last);
+		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
+		const int dev = fm_dev_nrzs((int)(int16_t)(cur.x & 0xffff), (int)cur.x >> 16, (int)(int16_t)(cur.y & 0xffff),
+					    (int)cur.y >> 16);
+		// the peak detector, wave-uniform (tfa1.cpp:157-160); mark >= 0 always, so (int) truncation is exact
+		for (int k = 0; k < nv; k++) {
+			const int dk = __builtin_amdgcn_readlane(dev, k);
+			mark = dk > mark ? dk : (int)((double)mark * 0.95);
+			lds_m[k] = mark;
+		}
+		__syncthreads();
+		const int mk = lds_m[lane];
+		__syncthreads();
+		const bool valid = lane < nv;
+		if (valid && mk > rssi_lane)
+			rssi_lane = mk;  // tfa1.cpp:161-162
+		unsigned long long m = __ballot(valid && dev < mk / 2);  // tfa1.cpp:164
+		while (m) {
+			const int k0 = __builtin_ctzll(m);
+			const unsigned long long inv = ~(m >> k0);
+			int len = inv ? __builtin_ctzll(inv) : 64 - k0;  // run of consecutive candidates
+			const int g0 = gb + k0;
+			const int left_in_block = kBlockDec - (g0 & (kBlockDec - 1));
+			if (len > left_in_block)
+				len = left_in_block;  // last_bit_idx is rebased at every block start: cut the run there
+			m = (k0 + len >= 64) ? 0ull : (m & (~0ull << (k0 + len)));
+			const int b = g0 >> 13;
+			if (b != cur_block) {
+				lbi = rebase_lbi(lbi, cur_block, b);
+				cur_block = b;
+			}
+			const int i0 = 2 * (g0 & (kBlockDec - 1));
+			// first sample of the run: tfa1.cpp:165-177
+			if (lbi) {
+				const int gap = i0 - lbi;
+				if (gap > 4) {
+					bw.put_run(1, gap >= 22 ? (gap - 22) / 20 + 1 : 0);  // ones for n = 22, 42, ... <= gap
+					bw.put_run(0, 1);
+				}
+			}
+			if (i0 - lbi > 2)
+				lbi = i0;
+			// the rest of the run: every gap is <= 4, so nothing is emitted; last_bit_idx follows "index - lbi > 2"
+			if (len > 1) {
+				const int d = i0 - lbi;               // 0 (just set) or 2
+				const int t1 = d >= 2 ? 1 : 2;        // first t >= 1 with i0 + 2t - lbi > 2
+				if (t1 <= len - 1)
+					lbi = i0 + 2 * t1 + 4 * ((len - 1 - t1) >> 1);
+			}
+		}
+	}
+	const int bl = last >> 13;
+	if (bl != cur_block) {
+		lbi = rebase_lbi(lbi, cur_block, bl);
+		cur_block = bl;
+	}
+	bw.finish();
+	// rssi = max over the lanes
+	int rssi = rssi_lane;
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) {
+		const int v = __shfl_xor(rssi, o, 64);
+		rssi = v > rssi ? v : rssi;
+	}
+	if (lane == 0) {
+		WinResult r;
+		r.nbits = bw.n;
+		r.closed = closed ? 1 : 0;
+		r.rssi_i = rssi;
+		r.offset = 0;
+		r.lbi_out = lbi;
+		r.first_cand_g = -1;
+		r.bitcnt = 0;
+		r.dmin = 32767;
+		r.dmax = -32767;
+		r.last_bit = 0;
+		r.mark_lvl = mark;
+		r.resume = -1;
+		T.result[(size_t)c * T.cap + j] = r;
+	}
+}
+
+__global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+							 const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
+							 ChainLaunch L, WinTables T)
+{
+	__shared__ int lds_m[64];
+	const int M = n_blocks * kBlockDec;
+	const size_t total = (size_t)L.n_active * n_streams * T.cap;
+	const int kind = blockIdx.y;
+	const int q = 2 * kind;  // the long windows of this kind
+	const uint32_t count = T.queue[q].count;
+	for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {  // wave-uniform
+		const uint2 it = T.items[(size_t)q * total + idx];
+		const int c = __builtin_amdgcn_readfirstlane((int)it.x), j = __builtin_amdgcn_readfirstlane((int)it.y);
+		if (kind == 0)
+			coop_tfa1(c, j, n_streams, M, dec, dec_stride, L, T, lds_m);
+		else
+			coop_tfa2(c, j, n_streams, M, ld16, L, T);
 	}
 }
 
@@ -1252,7 +1529,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
 				res.lbi_out = 0;
 				res.first_cand_g = -1;
-				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = res.pad_ = 0;
+				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
+				res.resume = -1;
 				if (ln == 0 && live)
 					T.result[(size_t)c * T.cap + j] = res;
 				nent = 0;
@@ -1432,7 +1710,7 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 						if (!same) {
 							atomicAdd(&T.stats[3], 1ull);
 							window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
-								       rebase_lbi(lbi, lbi_block, og >> 13), my_lds);
+								       rebase_lbi(lbi, lbi_block, og >> 13), my_lds, false);
 						}
 						lbi = rr->lbi_out;
 					} else {
@@ -1553,9 +1831,14 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	// biquad segments: at most (M/32 + windows)/kSegSlots + 1 per chain
 	const int seg_blocks = std::min(16384, (int)(((size_t)L.n_active * n_streams * ((size_t)n_blocks * (kBlockDec / 32) / kSegSlots + 4) +
 						       lanes_win - 1) / lanes_win));
+	static const int long_window = env_int("TFREC_AMD_COOP_MIN", kLongWindow);
+	// long windows: at most M / long_window per chain
+	const int coop_blocks = std::min(32768, std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
+								((size_t)n_blocks * kBlockDec / (size_t)std::max(long_window, 356) + 1), 1u << 30)));
 	(void)slicer_waves;
 	mark(0, st);
-	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T);
+	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T,
+			   long_window);
 	mark(1, st);
 	// Two independent kernel chains after the window scan (they touch disjoint state):
 	//   aux stream : WHB   spec_biquad -> fix_biquad -> whb_demod_kernel -> whb_commit_kernel
@@ -1605,6 +1888,9 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	mark(3, st);
 	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
 			   lanes_win);
+	if (!env_int("TFREC_AMD_NO_COOP", 0))
+		hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L,
+			   T);
 	mark(4, st);
 	hipLaunchKernelGGL(commit_kernel, grid, block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
 			   events, eb, flags, lanes_chain);

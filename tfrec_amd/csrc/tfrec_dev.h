@@ -102,7 +102,7 @@ struct WinResult {
 	int32_t lbi_out;       // last_bit_idx after the window, relative to the block of its last sample
 	int32_t first_cand_g;  // tfa2: first sample whose slicer saw a candidate edge (-1: none) -- speculation check
 	int32_t bitcnt, dmin, dmax, last_bit, mark_lvl;  // slicer state (needed when the window stays open)
-	int32_t pad_;
+	int32_t resume;        // long windows: first 32-sample slot the cooperative slicer still has to do (-1: none)
 };
 
 // full biquad state at the end of a window (speculative or repaired run)
@@ -113,6 +113,8 @@ struct BiquadEnd {
 struct WorkQueue {
 	uint32_t count;  // items pushed
 	uint32_t head;   // items taken
+	uint32_t head2;  // items taken by a second pass over the same queue
+	uint32_t pad_;
 };
 
 struct WinTables {
@@ -126,8 +128,7 @@ struct WinTables {
 	WinResult *result;      // [chains*cap]
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
 	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
-	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment).  The heads of
-	                        // queues 5 / 7 serve the repair pass over the same items.
+	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment)
 	WorkQueue *queue;       // [8]
 	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
 	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
@@ -146,7 +147,7 @@ struct WinTables {
 constexpr int kNQueues = 8;
 constexpr int kSegSlots = 128;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
 constexpr int kSegConverged = 0x40000000;
-constexpr int kLongWindow = 6000;  // samples; longer windows are handed out first (tail balance)
+constexpr int kLongWindow = 2048;  // samples; longer windows go to the wave-cooperative slicers (default)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
 static_assert(offsetof(tfrec_amd_event, rdata) == 32, "event rdata offset");
