@@ -105,6 +105,15 @@ struct WinResult {
 	int32_t resume;        // long windows: first 32-sample slot the cooperative slicer still has to do (-1: none)
 };
 
+// decoder::store_bit over ONE window's bits (TFA_1 / TFA_2 family), done window-parallel by decode_kernel
+struct WinDecode {
+	uint32_t sr;       // decoder registers after the window's last bit (before the flush)
+	int32_t sr_cnt, byte_cnt, invert;
+	int32_t wlen;      // rdata[0 .. wlen) were (re)written by this window (window 0 of a chain: all 64)
+	int32_t pad_[3];
+	uint8_t vals[64];  // rdata[0 .. 64) as the window leaves them (valid below wlen)
+};
+
 // full biquad state at the end of a window (speculative or repaired run)
 struct BiquadEnd {
 	double dn1, dn2, yn, yn1;
@@ -126,6 +135,7 @@ struct WinTables {
 	int32_t *open;          // [chains*cap] first sample of the window
 	int32_t *close;         // [chains*cap] sample at which the window's flush fires (>= M: after this submit)
 	WinResult *result;      // [chains*cap]
+	WinDecode *decode;      // [chains*cap]
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
 	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
 	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment)
