@@ -312,7 +312,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		};
 		const size_t o_count = carve(chains * 4), o_cont = carve(chains * 4), o_tnext = carve(chains * 4);
 		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
-		const size_t o_dcd = carve(wins * sizeof(WinDecode));
+		const size_t o_dcd = carve(wins * sizeof(WinDecode)), o_wst = carve(whb ? n * (size_t)T.cap * sizeof(WhbStart) : 0);
 		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve(kNQueues * wins * sizeof(uint2));
 		const size_t o_queue = carve(kNQueues * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(64);
 		T.segcap = (int32_t)((m_max / 32 + (size_t)T.cap) / kSegSlots + 2);
@@ -330,6 +330,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.close = (int32_t *)(b + o_close);
 			T.result = (WinResult *)(b + o_res);
 			T.decode = (WinDecode *)(b + o_dcd);
+			T.whbstart = (WhbStart *)(b + o_wst);
 			T.bits = (uint32_t *)(b + o_bits);
 			T.items = (uint2 *)(b + o_items);
 			T.queue = (WorkQueue *)(b + o_queue);

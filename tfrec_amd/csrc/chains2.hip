@@ -18,7 +18,7 @@
 //                       influence a window through its first candidate edge, so windows are run assuming a
 //                       far-away last edge and the assumption is checked (and the window re-run exactly) in K5.
 //                       Output: the bits handed to decoder::store_bit, packed.
-//   K4' whb_demod_kernel  32 lanes per stream: WHB stage 2 (decision-level biquad, phase-change detector); the
+//   K4' whb_demod_kernel  wave per stream: WHB stage 2 (decision-level biquad, phase-change detector); the
 //                       demodulator needs the decoder's has_sync() (whb.cpp:653, 677, 693), which is tracked
 //                       with a lane-parallel evaluation of the (GF(2)-linear) sync search.  Output: bit runs.
 //   K4'' whb_commit_kernel lane per stream: whb_decoder::store_bit over the runs, flush events.
@@ -1313,14 +1313,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 						       ChainLaunch L, int a, WinTables T)
 {
-	__shared__ double2 pb_lds[64];
-	__shared__ double y_lds[64];
-	const int grp = threadIdx.x >> 5, ln = threadIdx.x & 31;
-	const int s_raw = blockIdx.x * 2 + grp;
-	const bool live = s_raw < n_streams;
-	const int s = live ? s_raw : n_streams - 1;  // a dead half-wave shadows the last stream and never writes
-	double2 *pb = pb_lds + 32 * grp;
-	double *yl = y_lds + 32 * grp;
+	__shared__ double2 pb[64];
+	__shared__ double yl[64];
+	constexpr int kStep = 64;  // samples per iteration: one per lane
+	const int ln = threadIdx.x;
+	const int s = blockIdx.x;  // one wave per stream
 	const ChainParams &p = L.params[a];
 	ChainState &st = L.states[a][s];
 	const int c = a * n_streams + s;
@@ -1335,7 +1332,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	const int spb_i = (int)spb;
 	const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
 	const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
-	// ---- per-stream state, replicated in the 32 lanes of the stream
+	// ---- per-stream state, wave-uniform
 	Biquad f = st.iir_avg;
 	int avg_of = st.avg_of, last_dev = st.last_dev;
 	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
@@ -1349,14 +1346,16 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	uint32_t srr = __brev(st.sr);          // whb_decoder::sr, newest bit at the LSB
 	uint32_t nh = st.lfsr;                 // history of nrzs, newest at the LSB (whb.cpp:579)
 	const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
-	const int count = live ? T.count[c] : 0;
+	// sr_cnt / byte_cnt while the decoder has not locked since its last flush (they only matter before a stream's
+	// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
+	int sc = st.sr_cnt, bc = st.byte_cnt;
+	const int count = T.count[c];
 	const bool cont = T.cont[c] != 0;
 
-	// sum over the 32 lanes of the stream
-	auto group_sum = [&](unsigned long long v) -> unsigned long long {
+	auto wave_sum = [&](unsigned long long v) -> unsigned long long {
 #pragma unroll
-		for (int o = 16; o >= 1; o >>= 1)
-			v += __shfl_xor(v, o, 32);
+		for (int o = 32; o >= 1; o >>= 1)
+			v += __shfl_xor(v, o, 64);
 		return v;
 	};
 	// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
@@ -1367,10 +1366,17 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;    // descrambled bits, whb.cpp:578
 		const unsigned long long sv = ((unsigned long long)srr << len) | orun;
 		const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
-		const unsigned long long bal = __ballot(hit);
 		nh = (uint32_t)hn;
 		srr = (uint32_t)sv;
-		return ((uint32_t)(bal >> (32 * grp))) != 0u;
+		return __ballot(hit) != 0ull;
+	};
+	// sr_cnt / byte_cnt over `len` bits without a sync word (whb.cpp:590-596)
+	auto count_bits = [&](int len) {
+		if (sc >= 0) {
+			const int i0 = (8 - sc) & 7;  // first bit of the run that finds sr_cnt == 0
+			bc += i0 < len ? (len - 1 - i0) / 8 + 1 : 0;
+			sc = (sc + len) & 7;
+		}
 	};
 	struct Win {
 		int og, n, nch, slot0, closed;
@@ -1382,81 +1388,104 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		const int close = T.close[(size_t)c * T.cap + jc];
 		r.closed = close < M;
 		r.n = (r.closed ? close : M - 1) - r.og + 1;
-		r.nch = (r.n + kChunk - 1) >> 5;
+		r.nch = (r.n + kStep - 1) / kStep;
 		r.slot0 = win_slot0(r.og, jc);
 		return r;
 	};
-	Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
-	int j = 0, i = 0, nent = 0;
-	int dev_cur = count > 0 ? dvrow[(size_t)cw.slot0 * 32 + ln] : 0;
-	while (true) {
-		const bool act = j < count;
-		if (__ballot(act) == 0ull)
-			break;
-		// ---- (1) this slot's inputs; the next slot's sample is already in flight
-		const int nv = act ? (cw.n - kChunk * i < kChunk ? cw.n - kChunk * i : kChunk) : 0;
-		const int ns = (i + 1 < cw.nch) ? cw.slot0 + i + 1 : (j + 1 < count ? nw.slot0 : cw.slot0 + i);
-		const int dev_nxt = act ? dvrow[(size_t)ns * 32 + ln] : 0;
-		const int dev = dev_cur;
-		const uint32_t iqw = act ? drow[cw.og + kChunk * i + ln] : 0u;  // the lane's decimated sample (for the rssi)
-		const int devm1 = __shfl_up(dev, 1, 32), devm2 = __shfl_up(dev, 2, 32);
-		const bool rise = dev > (ln >= 1 ? devm1 : last_dev);  // dev > last_dev, whb.cpp:663
-		const bool unsynced0 = act && !synced;
-		const int nv_ser = unsynced0 ? nv : 0;
-		const int nmax = max(__shfl(nv_ser, 0, 64), __shfl(nv_ser, 32, 64));  // wave-uniform
-		int avgn = avg_of;
-		if (nmax > 0) {
-			const double dn = 0.5 * (double)dev;  // whb.cpp:654
-			const double dn1 = ln >= 1 ? 0.5 * (double)devm1 : f.dn1;
-			const double dn2 = ln >= 2 ? 0.5 * (double)devm2 : (ln == 1 ? f.dn1 : f.dn2);
-			pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
-			__syncthreads();
-			// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association)
-			double y1 = f.yn, y2 = f.yn1;
-#pragma unroll 4
-			for (int k = 0; k < nmax; k++) {
-				const double2 v = pb[k];
-				const double y = ((v.y + cavg.a1 * y1) + v.x) + cavg.a2 * y2;
-				yl[k] = y;
-				y2 = y1;
-				y1 = y;
-			}
-			__syncthreads();
-			// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
-			if (unsynced0)
-				avgn = (int)yl[ln];
-		}
-		// ---- (3) candidates: dev < avg_of && dev > last_dev
-		const unsigned long long bal = __ballot(act && ln < nv && dev < avgn && rise);
-		uint32_t mask = (uint32_t)(bal >> (32 * grp));
-		if (act) {
+	// the lane's stage-1 output and the two before it (the first lanes take theirs from the carried state)
+	struct Dev3 {
+		int d0, d1, d2;
+	};
+	auto load_dev = [&](int slot0, int i) -> Dev3 {
+		const int idx = slot0 * 32 + kStep * i + ln;
+		Dev3 r;
+		r.d0 = dvrow[idx];
+		r.d1 = dvrow[idx > 0 ? idx - 1 : 0];
+		r.d2 = dvrow[idx > 1 ? idx - 2 : 0];
+		return r;
+	};
+	if (count > 0) {
+		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
+		int j = 0, i = 0, nent = 0;
+		Dev3 cur = load_dev(cw.slot0, 0);
+		int pd1 = 0, pd2 = 0;  // stage-1 outputs of the two samples before this step (same window)
+		while (j < count) {
+			// ---- (1) this step's inputs; the next step's are already in flight
+			const int nv = cw.n - kStep * i < kStep ? cw.n - kStep * i : kStep;
+			const bool wnext = i + 1 >= cw.nch;
+			const Dev3 nxt = load_dev(wnext ? (j + 1 < count ? nw.slot0 : cw.slot0) : cw.slot0, wnext ? 0 : i + 1);
 			const int og = cw.og, n = cw.n;
-			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
-			if (i == 0 && !(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
-				rssi_d = 0;
-				rssi_acc = 0;
-				step0 = 0;
-				last_peak = 0;
+			uint32_t iqw = 0;  // the lane's decimated sample (rssi: only while the decoder is locked)
+			if (synced)
+				iqw = drow[og + kStep * i + ln];
+			const int dev = cur.d0;
+			const int devm1 = ln >= 1 ? cur.d1 : pd1;
+			const int devm2 = ln >= 2 ? cur.d2 : (ln == 1 ? pd1 : pd2);
+			if (i == 0) {
+				if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
+					rssi_d = 0;
+					rssi_acc = 0;
+					step0 = 0;
+					last_peak = 0;
+				}
+				if (ln == 0) {
+					WhbStart ws;
+					ws.sr = __brev(srr);
+					ws.lfsr = nh;
+					ws.sr_cnt = sc;
+					ws.byte_cnt = bc;
+					ws.synced = synced;
+					ws.pad_[0] = ws.pad_[1] = ws.pad_[2] = 0;
+					T.whbstart[(size_t)s * T.cap + j] = ws;
+				}
 			}
-			const long long base_step = step0 + (long long)kChunk * i;
+			// dev > last_dev (whb.cpp:663); the window's first sample compares with the carried last_dev
+			const bool rise = dev > ((i == 0 && ln == 0) ? last_dev : devm1);
+			const bool unsynced0 = !synced;
+			int avgn = avg_of;
+			if (unsynced0) {
+				const double dn = 0.5 * (double)dev;  // whb.cpp:654
+				const bool first = i == 0;     // the window's first samples continue the carried filter inputs
+				const double dn1 = (first && ln == 0) ? f.dn1 : 0.5 * (double)devm1;
+				const double dn2 = (first && ln == 0) ? f.dn2 : ((first && ln == 1) ? f.dn1 : 0.5 * (double)devm2);
+				pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
+				__syncthreads();
+				// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association)
+				double y1 = f.yn, y2 = f.yn1;
+#pragma unroll 4
+				for (int k = 0; k < nv; k++) {
+					const double2 v = pb[k];
+					const double y = ((v.y + cavg.a1 * y1) + v.x) + cavg.a2 * y2;
+					yl[k] = y;
+					y2 = y1;
+					y1 = y;
+				}
+				__syncthreads();
+				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
+				avgn = (int)yl[ln];
+			}
+			// ---- (3) candidates: dev < avg_of && dev > last_dev
+			unsigned long long mask = __ballot(ln < nv && dev < avgn && rise);
+			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
+			const long long base_step = step0 + (long long)kStep * i;
 			bool locked_here = false;
-			int rssi_from = synced ? 0 : kChunk;  // first sample of the slot that counts for the rssi
+			int rssi_from = synced ? 0 : kStep;  // first sample of the step that counts for the rssi
 			// ---- (4) accepted candidates
 			while (mask) {
 				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
-				if (kmin > 31)
+				if (kmin > kStep - 1)
 					break;
 				if (kmin > 0)
-					mask &= ~0u << (int)kmin;
+					mask &= ~0ull << (int)kmin;
 				if (!mask)
 					break;
-				const int k = __builtin_ctz(mask);
+				const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
 				mask &= mask - 1;
 				const int tdiff = (int)(base_step + k - last_peak);
 				// whb.cpp:666-673: one 0, then (bit0 - 1) ones
 				const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
 				const int len = bit0 > 1 ? bit0 : 1;
-				if (ln == 0 && live) {
+				if (ln == 0) {
 					if (len < kWhbRunEsc) {
 						ent[nent] = (uint16_t)len;
 					} else {
@@ -1471,37 +1500,44 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				bool hit = feed(~1u, len < 32 ? len : 32);
 				for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
 					hit = feed(~0u, rest < 32 ? rest : 32) || hit;
+				if (!synced)
+					count_bits(len);
 				last_peak = base_step + k;
 				if (!synced && hit) {  // the decoder locked at sample k: rssi counts from k on (:677)
 					synced = 1;
 					rssi_from = k;
+					if (!iqw && rssi_from < nv)
+						iqw = drow[og + kStep * i + ln];
 					// the average stops after sample k (whb.cpp:653): state and avg_of as of k, and the rest of
-					// the slot's candidates against the frozen avg_of
+					// the step's candidates against the frozen avg_of
 					const double yk = yl[k], ykm1 = yl[k > 0 ? k - 1 : 0];
-					const int dk = __shfl(dev, k, 32), dkm1 = __shfl(dev, k > 0 ? k - 1 : 0, 32);
+					const int dk = __builtin_amdgcn_readlane(dev, k);
+					const int dkm1 = k > 0 ? __builtin_amdgcn_readlane(dev, k > 0 ? k - 1 : 0) : 0;
 					f.yn1 = k > 0 ? ykm1 : f.yn;
 					f.yn = yk;
-					f.dn2 = k > 0 ? 0.5 * (double)dkm1 : f.dn1;
+					f.dn2 = k > 0 ? 0.5 * (double)dkm1 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
 					f.dn1 = 0.5 * (double)dk;
 					avg_of = (int)yk;
-					const unsigned long long b2 = __ballot(ln < nv && ln > k && dev < avg_of && rise);
-					mask = (uint32_t)(b2 >> (32 * grp));
+					mask = __ballot(ln < nv && ln > k && dev < avg_of && rise);
 					locked_here = true;
 				}
 			}
-			if (unsynced0 && !locked_here) {  // the whole slot went through the average
+			const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
+			const int dl2 = nv > 1 ? __builtin_amdgcn_readlane(dev, nv > 1 ? nv - 2 : 0) : pd1;
+			if (unsynced0 && !locked_here) {  // the whole step went through the average
 				const double ye = yl[nv - 1], yem1 = yl[nv > 1 ? nv - 2 : 0];
-				const int dkm1 = __shfl(dev, nv > 1 ? nv - 2 : 0, 32);
 				f.yn1 = nv > 1 ? yem1 : f.yn;
 				f.yn = ye;
-				f.dn2 = nv > 1 ? 0.5 * (double)dkm1 : f.dn1;
-				f.dn1 = 0.5 * (double)__shfl(dev, nv - 1, 32);
+				f.dn2 = nv > 1 ? 0.5 * (double)dl2 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
+				f.dn1 = 0.5 * (double)dl1;
 				avg_of = (int)ye;
 			}
-			last_dev = __shfl(dev, nv - 1, 32);
+			last_dev = dl1;
+			pd2 = dl2;
+			pd1 = dl1;
 			if (rssi_from < nv) {  // whb.cpp:677-678
 				const int I = (int)(int16_t)(iqw & 0xffff), Q = (int)iqw >> 16;
-				rssi_acc += group_sum(ln >= rssi_from && ln < nv ? (unsigned long long)(uint32_t)(I * I + Q * Q) : 0ull);
+				rssi_acc += wave_sum(ln >= rssi_from && ln < nv ? (unsigned long long)(uint32_t)(I * I + Q * Q) : 0ull);
 			}
 			if (i == cw.nch - 1) {  // last sample of the window in this submit
 				WinResult res;
@@ -1515,6 +1551,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 						res.closed = 1;
 						srr = 0;
 						synced = 0;
+						sc = -1;
+						bc = 0;
 					}
 					rssi_d = 0;
 					rssi_acc = 0;
@@ -1531,11 +1569,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				res.first_cand_g = -1;
 				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
 				res.resume = -1;
-				if (ln == 0 && live)
+				if (ln == 0)
 					T.result[(size_t)c * T.cap + j] = res;
 				nent = 0;
 			}
-			dev_cur = dev_nxt;
+			cur = nxt;
 			if (++i >= cw.nch) {
 				j++;
 				i = 0;
@@ -1545,7 +1583,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			}
 		}
 	}
-	if (live && ln == 0) {
+	if (ln == 0) {
 		const uint32_t lw = drow[M - 1];
 		st.prev_i = (int)(int16_t)(lw & 0xffff);
 		st.prev_q = (int)lw >> 16;
@@ -1976,7 +2014,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		mark(6, ws);
 		for (int a = 0; a < L.n_active; a++)
 			if (L.params[a].kind == 2) {
-				hipLaunchKernelGGL(whb_demod_kernel, dim3((n_streams + 1) / 2), block, 0, ws, dec, dec_stride, dev32,
+				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, 0, ws, dec, dec_stride, dev32,
 						   n_streams, n_blocks, L, a, T);
 				hipLaunchKernelGGL(whb_commit_kernel, dim3((n_streams + 63) / 64), block, 0, ws, dec, dec_stride, n_streams,
 						   n_blocks, sample_base, L, a, T, events, eb, flags);

@@ -114,6 +114,13 @@ struct WinDecode {
 	uint8_t vals[64];  // rdata[0 .. 64) as the window leaves them (valid below wlen)
 };
 
+// whb_decoder registers at the first bit of a window, as tracked by whb_demod_kernel (window-parallel replay)
+struct WhbStart {
+	uint32_t sr, lfsr;
+	int32_t sr_cnt, byte_cnt, synced;
+	int32_t pad_[3];
+};
+
 // full biquad state at the end of a window (speculative or repaired run)
 struct BiquadEnd {
 	double dn1, dn2, yn, yn1;
@@ -136,6 +143,7 @@ struct WinTables {
 	int32_t *close;         // [chains*cap] sample at which the window's flush fires (>= M: after this submit)
 	WinResult *result;      // [chains*cap]
 	WinDecode *decode;      // [chains*cap]
+	WhbStart *whbstart;     // [n_streams*cap]
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
 	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
 	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment)
