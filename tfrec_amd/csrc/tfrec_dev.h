@@ -109,10 +109,13 @@ struct WinResult {
 struct WinDecode {
 	uint32_t sr;       // decoder registers after the window's last bit (before the flush)
 	int32_t sr_cnt, byte_cnt, invert;
-	int32_t wlen;      // rdata[0 .. wlen) were (re)written by this window (window 0 of a chain: all 64)
-	int32_t pad_[3];
-	uint8_t vals[64];  // rdata[0 .. 64) as the window leaves them (valid below wlen)
+	int32_t wlen;      // TFA: rdata[0 .. wlen) were (re)written by this window (window 0 of a chain: all 64)
+	uint32_t lfsr;     // WHB: descrambler history after the window; `invert` then holds kWhbF* flags
+	unsigned long long wmask;  // WHB: bit b = rdata[b] was written by this window (window 0: all ones)
+	uint8_t vals[64];  // rdata[0 .. 64) as the window leaves them (valid where written)
 };
+constexpr int kWhbFPsk = 1, kWhbFSynced = 2, kWhbFLastBit = 4, kWhbFNrzs = 8;
+static_assert(sizeof(WinDecode) == 96, "WinDecode layout");
 
 // whb_decoder registers at the first bit of a window, as tracked by whb_demod_kernel (window-parallel replay)
 struct WhbStart {
@@ -146,7 +149,8 @@ struct WinTables {
 	WhbStart *whbstart;     // [n_streams*cap]
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
 	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
-	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment)
+	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment); queue 5: WHB
+	                        // windows (chain, j)
 	WorkQueue *queue;       // [8]
 	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
 	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
