@@ -94,8 +94,9 @@ def load_library(build: bool = True):
             _build.build_device_lib()
         except (OSError, FileNotFoundError):
             pass  # no hipcc on this box: use the prebuilt library that travelled with the tree
-    if not os.path.exists(_build.LIB_SO):
-        raise RuntimeError("HIP extension %s is missing: run __graft_entry__.build()" % _build.LIB_SO)
+    lib_so = os.environ.get("TFREC_AMD_LIB", _build.LIB_SO)  # (A/B experiments: an alternative build of the library)
+    if not os.path.exists(lib_so):
+        raise RuntimeError("HIP extension %s is missing: run __graft_entry__.build()" % lib_so)
     # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing torch first makes our
     # library bind to that same copy (same SONAME) instead of loading /opt/rocm's next to it, which would
     # leave whichever runtime comes second without a GPU.
@@ -103,7 +104,7 @@ def load_library(build: bool = True):
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(_build.LIB_SO)
+    L = C.CDLL(lib_so)
     L.tfrec_amd_version.restype = C.c_char_p
     L.tfrec_amd_strerror.restype = C.c_char_p
     L.tfrec_amd_strerror.argtypes = [C.c_int]
@@ -228,7 +229,9 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:4]}
+        out = {n: int(getattr(st, n)) for n, _ in Stats._fields_[:4]}
+        out["reserved"] = [int(x) for x in st.reserved]
+        return out
 
 
 def event_tuples(events: np.ndarray, stream: int | None = None):

@@ -832,12 +832,13 @@ struct Slot4 {
 // Run one window [g0, last] of a TFA_1 (KIND 0) or TFA_2-family (KIND 1) slicer.  Each 32-sample chunk is moved
 // from registers to the lane's LDS column, the next chunk's loads are issued, then the chunk is walked from
 // LDS by a rolled loop (small code, HBM latency overlapped with the state machine).
-// handoff (TFA_2 family, long windows): stop after the chunk in which bitcnt reached 10 -- from there on the
-// thresholds are frozen and the wave-cooperative slicer takes over.  Returns the first chunk NOT done (nch: all).
+// head_chunks > 0 (TFA_2 family, long windows): stop after the chunk in which bitcnt reached 10 (the thresholds
+// are frozen from there on), at the latest after head_chunks chunks; the wave-cooperative slicer takes over.
+// Returns the first chunk NOT done (nch: all).
 template <int KIND>
 __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int last, bool closed,
 					  const uint32_t *__restrict__ drow, const uint32_t *__restrict__ ldslots, int prevI,
-					  int prevQ, double spb, uint4 *__restrict__ my_lds, bool handoff)
+					  int prevQ, double spb, uint4 *__restrict__ my_lds, int head_chunks)
 {
 	const int n = last - g0 + 1;
 	const int nch = (n + kChunk - 1) >> 5;
@@ -915,7 +916,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 			}
 			bw.chunk_end();
 			cur = nxt;
-			if (handoff && f.bitcnt >= 10 && i + 1 < nch)
+			if (head_chunks > 0 && (f.bitcnt >= 10 || i + 1 >= head_chunks) && i + 1 < nch)
 				return i + 1;
 		}
 	}
@@ -934,7 +935,7 @@ template <int KIND>
 __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					    size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
 					    const WinTables &T, bool exact_lbi, int lbi_in_override, uint4 *__restrict__ my_lds,
-					    bool handoff)
+					    int head_chunks)
 {
 	const int a = c / n_streams, s = c - a * n_streams;
 	const ChainParams &p = L.params[a];
@@ -970,7 +971,8 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
 							(size_t)win_slot0(og, j) * 16
 					      : nullptr;
-	const int resume = run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, my_lds, handoff);
+	const int resume = run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, my_lds,
+					    head_chunks);
 	bw.finish();
 	WinResult &r = T.result[(size_t)c * T.cap + j];
 	r.resume = resume < ((last - og + 1 + kChunk - 1) >> 5) ? resume : -1;
@@ -988,13 +990,13 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-// Persistent lanes pull (chain, window) items.  blockIdx.y = protocol kind (0 TFA_1, 1 TFA_2 family), each with
-// its own pair of queues, so a wave runs one slicer type.  Short windows are sliced completely; of the long
-// TFA_2-family windows only the head (until the thresholds freeze, tfa2.cpp:363 "bitcnt < 10") -- the rest,
-// and the long TFA_1 windows, belong to coop_slicer_kernel.
+// Lane per window.  blockIdx.y = protocol kind (0 TFA_1, 1 TFA_2 family), so a wave runs one slicer type.  Short
+// windows are sliced completely.  Of the long TFA_2-family windows only the head, where the thresholds still
+// adapt sample by sample (tfa2.cpp:363 "bitcnt < 10"; cheap per window when 64 windows share a wave, expensive
+// for a whole wave) -- the rest, and the long TFA_1 windows, belong to coop_slicer_kernel.
 __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks, ChainLaunch L,
-						    WinTables T, int lanes)
+						    WinTables T, int lanes, int head_chunks)
 {
 	__shared__ uint4 slot_lds[8 * 64];
 	uint4 *my_lds = slot_lds + threadIdx.x;
@@ -1005,7 +1007,7 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 	const int kind = blockIdx.y;
 	for (int q = 2 * kind + (kind == 0 ? 1 : 0); q < 2 * kind + 2; q++) {
 		const uint32_t count = T.queue[q].count;
-		const bool handoff = (q & 1) == 0;
+		const int head = (q & 1) == 0 ? head_chunks : 0;
 		while (true) {
 			const uint32_t idx = atomicAdd(&T.queue[q].head, 1u);
 			if (idx >= count)
@@ -1013,9 +1015,9 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 			const uint2 it = T.items[(size_t)q * total + idx];
 			const int c = (int)it.x, j = (int)it.y;
 			if (kind == 0)
-				window_task<0>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds, false);
+				window_task<0>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds, 0);
 			else
-				window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds, handoff);
+				window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, false, 0, my_lds, head);
 		}
 	}
 }
@@ -1068,68 +1070,140 @@ struct CoopBits {
 	}
 };
 
-__device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, const int16_t *__restrict__ ld16,
-					  const ChainLaunch &L, const WinTables &T)
+__device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
+					  size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
+					  const WinTables &T)
 {
 	const int lane = threadIdx.x;
-	const int a = c / n_streams;
+	const int a = c / n_streams, s = c - a * n_streams;
 	const double spb = L.params[a].spb;
-	WinResult &rr = T.result[(size_t)c * T.cap + j];
-	const WinResult r0 = rr;
-	if (r0.resume < 0)
-		return;  // the lane-per-window pass finished the window
 	const int og = T.open[(size_t)c * T.cap + j];
 	const int close = T.close[(size_t)c * T.cap + j];
 	const bool closed = close < M;
 	const int last = closed ? close : M - 1;
-	const int g1 = og + kChunk * r0.resume;  // first sample still to do
+	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	const int16_t *ldrow = ld16 + (size_t)c * T.slots * 32 + (size_t)win_slot0(og, j) * 32;  // window-relative
-	// frozen thresholds (tfa2.cpp:379-381)
-	const int noffset = d2i(0.9 * r0.offset);
-	const int hi = noffset + r0.dmax / 32, lo = noffset + r0.dmin / 32;
-	int last_bit = r0.last_bit, bitcnt = r0.bitcnt, first_cand_g = r0.first_cand_g;
+	// ---- wave-uniform slicer state (tfa2.h:35-42): where the lane-per-window head (slicer_kernel) stopped
+	WinResult &rr = T.result[(size_t)c * T.cap + j];
+	const WinResult r0 = rr;
+	if (r0.resume < 0)
+		return;  // the head finished the window
+	const int g1 = og + kChunk * r0.resume;  // first sample still to do
+	int rssi_i = r0.rssi_i, bitcnt = r0.bitcnt, dmin = r0.dmin, dmax = r0.dmax, offset = r0.offset;
+	int last_bit = r0.last_bit, first_cand_g = r0.first_cand_g;
 	int cur_block = (g1 - 1) >> 13;
 	int lbi = r0.lbi_out;  // relative to cur_block (run_window leaves it relative to the block of its last sample)
+	// integer form of "tdiff > spb / 4 && tdiff < 32 * spb" (tdiff is an integer)
+	const int td_lo = (int)floor(spb / 4) + 1;
+	const int td_hi = (int)ceil(32 * spb) - 1;
+	int hi = 0, lo = 0;
+	auto thresholds = [&]() {  // tfa2.cpp:379-381
+		const int noffset = d2i(0.9 * offset);
+		hi = noffset + dmax / 32;
+		lo = noffset + dmin / 32;
+	};
+	thresholds();
 	CoopBits bw;
 	bw.init(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, r0.nbits);
-	int ld_nxt = g1 + lane <= last ? (int)ldrow[g1 - og + lane] : 0;
-	for (int gb = g1; gb <= last; gb += 64) {
-		const int ld = ld_nxt;
-		if (gb + 64 <= last)
-			ld_nxt = gb + 64 + lane <= last ? (int)ldrow[gb + 64 - og + lane] : 0;
-		const bool valid = gb + lane <= last;
-		const unsigned long long m1 = __ballot(valid && ld > hi);
-		const unsigned long long m0 = __ballot(valid && ld < lo) & ~m1;
-		unsigned long long todo = ~0ull;  // positions not yet visited
-		while (true) {
-			const unsigned long long m = (last_bit ? m0 : m1) & todo;
-			if (!m)
-				break;
-			const int k = __builtin_ctzll(m);
-			todo = k >= 63 ? 0ull : (~0ull << (k + 1));
-			const int g = gb + k;
-			const int b = g >> 13;
-			if (b != cur_block) {
-				lbi = rebase_lbi(lbi, cur_block, b);
-				cur_block = b;
+	// one candidate edge (tfa2.cpp:383-411)
+	auto candidate = [&](int g, int bit) {
+		const int b = g >> 13;
+		if (b != cur_block) {
+			lbi = rebase_lbi(lbi, cur_block, b);
+			cur_block = b;
+		}
+		const int index = 2 * (g & (kBlockDec - 1));
+		if (first_cand_g < 0)
+			first_cand_g = g;
+		if (index > lbi + 8) {  // tfa2.cpp:391-406
+			bitcnt++;
+			const int tdiff = index - lbi;
+			if (tdiff >= td_lo && tdiff <= td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
+				const int numbits = d2i(((tdiff / 2) + (spb / 2)) / spb);
+				if (numbits < 32)
+					bw.put_run(last_bit, numbits - 1);
+				bw.put_run(bit, 1);
+				last_bit = bit;
 			}
-			const int index = 2 * (g & (kBlockDec - 1));
-			const int bit = last_bit ^ 1;
-			if (first_cand_g < 0)
-				first_cand_g = g;
-			if (index > lbi + 8) {  // tfa2.cpp:391-406
-				bitcnt++;
-				const int tdiff = index - lbi;
-				if (tdiff > spb / 4 && tdiff < 32 * spb) {
-					const int numbits = d2i(((tdiff / 2) + (spb / 2)) / spb);
-					if (numbits < 32)
-						bw.put_run(last_bit, numbits - 1);
-					bw.put_run(bit, 1);
-					last_bit = bit;
+		}
+		if (index - lbi > 2)
+			lbi = index;
+	};
+	struct In {
+		int ld;
+		uint32_t iq;
+	};
+	auto load = [&](int gb) -> In {
+		In v;
+		const int g = gb + lane <= last ? gb + lane : last;
+		v.ld = (int)ldrow[g - og];
+		v.iq = bitcnt < 10 ? drow[g] : 0u;  // only the adaptive phase looks at the power (tfa2.cpp:371-375)
+		return v;
+	};
+	In nxt = load(g1);
+	for (int gb = g1; gb <= last; gb += 64) {
+		const In cur = nxt;
+		if (gb + 64 <= last)
+			nxt = load(gb + 64);
+		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
+		const bool valid = lane < nv;
+		const int ld = cur.ld;
+		if (bitcnt >= 10) {  // thresholds frozen: two ballots, then only the edges of the polarity that can flip last_bit
+			const unsigned long long m1 = __ballot(valid && ld > hi);
+			const unsigned long long m0 = __ballot(valid && ld < lo) & ~m1;
+			unsigned long long todo = ~0ull;  // positions not yet visited
+			while (true) {
+				const unsigned long long m = (last_bit ? m0 : m1) & todo;
+				if (!m)
+					break;
+				const int k = __builtin_ctzll(m);
+				todo = k >= 63 ? 0ull : (~0ull << (k + 1));
+				candidate(gb + k, last_bit ^ 1);
+			}
+			continue;
+		}
+		// I*I + Q*Q in the wrapping arithmetic of the reference binary (tfa2.cpp:373)
+		const int I = (int)(int16_t)(cur.iq & 0xffff), Q = (int)cur.iq >> 16;
+		const uint32_t pw = (uint32_t)(I * I) + (uint32_t)(Q * Q);
+		int pos = 0;
+		while (pos < nv) {
+			const unsigned long long rest = ~0ull << pos;
+			// next candidate edge under the current thresholds, next sample that moves the thresholds (tfa2.cpp:363-369)
+			const unsigned long long m1 = __ballot(valid && ld > hi);
+			const unsigned long long m0 = __ballot(valid && ld < lo) & ~m1;
+			const unsigned long long cand = (last_bit ? m0 : m1) & rest;
+			const int kc = cand ? __builtin_ctzll(cand) : 64;
+			int ku = 64;
+			if (bitcnt < 10) {
+				const unsigned long long u = __ballot(valid && (ld > dmax || ld < dmin)) & rest;
+				ku = u ? __builtin_ctzll(u) : 64;
+			}
+			const int ke = kc < ku ? kc : ku;
+			const int kend = ke < 64 ? ke : nv - 1;  // the stretch [pos, kend] has constant thresholds and bitcnt
+			if (bitcnt > 4 && bitcnt < 10) {  // tfa2.cpp:371-375, sample by sample (wrapping int32)
+				for (int k = pos; k <= kend; k++) {
+					const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
+					const uint32_t t = (uint32_t)rssi_i + pk;
+					rssi_i = (int)((uint32_t)rssi_i + (uint32_t)((int)t / 100));
 				}
 			}
-			if (index - lbi > 2)
-				lbi = index;
+			if (ke >= 64)
+				break;
+			if (ku <= kc) {  // the sample moves dmax / dmin; its own edge test uses the new thresholds
+				const int ldk = __builtin_amdgcn_readlane(ld, ku);
+				if (ldk > dmax)
+					dmax = (7 * dmax + ldk) / 8;
+				if (ldk < dmin)
+					dmin = (7 * dmin + ldk) / 8;
+				offset = (dmax + dmin) / 2;
+				thresholds();
+				const int bitk = ldk > hi ? 1 : 0;
+				if ((ldk > hi || ldk < lo) && bitk != last_bit)
+					candidate(gb + ku, bitk);
+			} else {
+				candidate(gb + kc, last_bit ^ 1);
+			}
+			pos = ke + 1;
 		}
 	}
 	const int bl = last >> 13;
@@ -1141,12 +1215,18 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		bw.put_run(last_bit, 16);
 	bw.finish();
 	if (lane == 0) {
-		WinResult r = r0;
+		WinResult r;
 		r.nbits = bw.n;
+		r.closed = closed ? 1 : 0;
+		r.rssi_i = rssi_i;
+		r.offset = offset;
 		r.lbi_out = lbi;
 		r.first_cand_g = first_cand_g;
 		r.bitcnt = bitcnt;
+		r.dmin = dmin;
+		r.dmax = dmax;
 		r.last_bit = last_bit;
+		r.mark_lvl = 0;
 		r.resume = -1;
 		rr = r;
 	}
@@ -1269,9 +1349,11 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 
 __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
-							 ChainLaunch L, WinTables T)
+							 ChainLaunch L, WinTables T, int kinds)
 {
 	__shared__ int lds_m[64];
+	if (!((kinds >> blockIdx.y) & 1))
+		return;  // (experiments: TFREC_AMD_COOP_KINDS)
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int kind = blockIdx.y;
@@ -1283,7 +1365,7 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 		if (kind == 0)
 			coop_tfa1(c, j, n_streams, M, dec, dec_stride, L, T, lds_m);
 		else
-			coop_tfa2(c, j, n_streams, M, ld16, L, T);
+			coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T);
 	}
 }
 
@@ -1950,7 +2032,7 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 					if (!same) {  // slice and decode this window again, exactly (rare)
 						atomicAdd(&T.stats[3], 1ull);
 						window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
-							       rebase_lbi(lbi, lbi_block, og >> 13), my_lds, false);
+							       rebase_lbi(lbi, lbi_block, og >> 13), my_lds, 0);
 						uint4 keep[4];
 #pragma unroll
 						for (int q = 0; q < 4; q++)
@@ -2087,7 +2169,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 						       lanes_win - 1) / lanes_win));
 	static const int long_window = env_int("TFREC_AMD_COOP_MIN", kLongWindow);
 	// long windows: at most M / long_window per chain
-	const int coop_blocks = std::min(32768, std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
+	const int coop_blocks = std::min(env_int("TFREC_AMD_COOP_BLOCKS", 8192), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
 								((size_t)n_blocks * kBlockDec / (size_t)std::max(long_window, 356) + 1), 1u << 30)));
 	const int dec_blocks = std::min(16384, std::max(1, win_blocks));
 	(void)slicer_waves;
@@ -2142,11 +2224,12 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	} else
 		mark(2, st);
 	mark(3, st);
+	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 48));
 	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
-			   lanes_win);
+			   lanes_win, head_chunks);
 	if (!env_int("TFREC_AMD_NO_COOP", 0))
 		hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L,
-			   T);
+				   T, env_int("TFREC_AMD_COOP_KINDS", 3));
 	mark(4, st);
 	hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks, 2), block, 0, st, n_streams, L, T);
 	hipLaunchKernelGGL(commit_kernel, grid, block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
