@@ -148,24 +148,30 @@ def main():
             print("PARITY FAILURE on rank %d" % rank, file=sys.stderr)
             sys.exit(3)
 
-    def step():
+    # Submits and drains form a FIFO of depth two (include/tfrec_amd.h): batch k+1 is queued before batch k's events
+    # are drained, so the GPU never waits for the host's copy + sort of the previous batch.
+    def run(n_steps, collect):
+        n_ev = 0
+        if n_steps < 1:
+            return 0
         r.submit(d_iq)
-        return r.drain()
+        for k in range(n_steps):
+            if k + 1 < n_steps:
+                r.submit(d_iq)
+            n_ev += len(r.drain())
+            if collect is not None:
+                t = r.timings()  # HIP events recorded on the streams the kernels of the drained batch ran on
+                for kk, v in t.items():
+                    collect.setdefault(kk, []).append(v)
+        return n_ev
 
-    for _ in range(a.warmup):
-        step()
+    run(a.warmup, None)
     kt = {}
-    n_events = 0
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ev = step()
-        n_events += len(ev)
-        t = r.timings()  # HIP events recorded on the streams the kernels were launched on
-        for k, v in t.items():
-            kt.setdefault(k, []).append(v)
+    n_events = run(a.steps, kt)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

@@ -114,12 +114,15 @@ int tfrec_amd_submit_host(tfrec_amd_ctx *ctx, const uint8_t *h_iq, size_t stream
 /* Wait for submitted work. */
 int tfrec_amd_sync(tfrec_amd_ctx *ctx);
 
-/* Wait, then copy the events produced since the last drain to out[0..cap), ordered by
- * (stream, slot, seq).  *n_out = number written.  Returns TFREC_AMD_E_OVERFLOW if the device buffer or
- * cap was too small (the events that fit are still returned). */
+/* Wait for the OLDEST submit that has not been drained yet, then copy its events to out[0..cap), ordered by
+ * (stream, slot, seq).  *n_out = number written (0 if nothing was submitted).  Returns TFREC_AMD_E_OVERFLOW if the
+ * device buffer or cap was too small (the events that fit are still returned).
+ * Submits and drains form a FIFO of depth two: a caller may queue submit k+1 before draining submit k, so that the
+ * GPU works on k+1 while the host copies and dispatches k's events; a third undrained submit is refused with
+ * TFREC_AMD_E_STATE.  Alternating submit / drain behaves as one would expect. */
 int tfrec_amd_drain_events(tfrec_amd_ctx *ctx, tfrec_amd_event *out, int cap, int *n_out);
 
-/* Number of events waiting (synchronises). */
+/* Number of events of the oldest undrained submit (waits for it). */
 int tfrec_amd_pending_events(tfrec_amd_ctx *ctx, int *n);
 
 /* The dB value the reference demodulator passes to decoder::flush for this slot, computed with the

@@ -192,3 +192,31 @@ def test_auto_threshold_matches_oracle(serial):
             assert r.thresh(s) == o.thresh(), "stream %d" % s
             moved += int(o.thresh() != 500)
         assert moved >= 2
+
+
+def test_two_submits_in_flight_fifo():
+    """Submit k+1 may be queued before submit k is drained (FIFO of depth two); a third one is refused."""
+    n_streams = 6
+    iq = synth.gen_batch(23, 5, n_streams, 30)
+    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 10), (10, 20), (20, 30))]
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=10, all_flushes=True) as r:
+        ref = []
+        for p in parts:
+            r.submit(p)
+            ref.append(r.drain())
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=10, all_flushes=True) as r:
+        import torch
+        dev = [torch.from_numpy(p).cuda() for p in parts]
+        got = []
+        r.submit(dev[0])
+        r.submit(dev[1])
+        with pytest.raises(RuntimeError):
+            r.submit(dev[2])  # two submits are waiting to be drained
+        got.append(r.drain())
+        r.submit(dev[2])
+        got.append(r.drain())
+        got.append(r.drain())
+        assert len(r.drain()) == 0
+    for a, b in zip(ref, got):
+        assert len(a) == len(b) and len(a) > 0
+        assert a.tobytes() == b.tobytes()

@@ -59,17 +59,26 @@ struct tfrec_amd_ctx {
 	int wmax = 0;
 	uint8_t *d_tail[2] = { nullptr, nullptr };
 	int tail_sel = 0;
-	tfrec_amd_event *d_events = nullptr;
-	EventBuf *d_eb = nullptr;
+	// Two event buffer sets: a submit may be queued while the host still drains the previous one (FIFO, depth 2)
+	tfrec_amd_event *d_events[2] = { nullptr, nullptr };
+	EventBuf *d_eb[2] = { nullptr, nullptr };
+	EventBuf *d_eb_fresh = nullptr;       // { 0, max_events, 0 }: copied over a set's EventBuf when a submit starts
+	tfrec_amd_event *h_events = nullptr;  // pinned staging for the drain
+	EventBuf *h_eb = nullptr;
+	hipEvent_t done[2] = { nullptr, nullptr };  // end of the submit that owns the set
+	hipStream_t copy = nullptr;           // non-blocking stream of the drain's device-to-host copies
+	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..2)
+	int last_drained = -1;
 	uint8_t *d_stage = nullptr;
 	size_t stage_bytes = 0;
 	long long sample_base = 0;
 	int last_blocks = 0;
 	hipStream_t last_stream = nullptr;
-	hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+	hipEvent_t ev[2][3] = { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } };
 	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	hipEvent_t tev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipEvent_t tev[2][8] = { { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr },
+				 { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr } };
 	bool whb_active = false;
 	bool timed = false;
 	unsigned long long uncertain_total = 0;
@@ -164,15 +173,26 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_fsk);
 	(void)hipFree(c->d_tail[0]);
 	(void)hipFree(c->d_tail[1]);
-	(void)hipFree(c->d_events);
-	(void)hipFree(c->d_eb);
+	for (int k = 0; k < 2; k++) {
+		(void)hipFree(c->d_events[k]);
+		(void)hipFree(c->d_eb[k]);
+		if (c->done[k])
+			(void)hipEventDestroy(c->done[k]);
+		for (auto &e : c->ev[k])
+			if (e)
+				(void)hipEventDestroy(e);
+		for (auto &e : c->tev[k])
+			if (e)
+				(void)hipEventDestroy(e);
+	}
+	(void)hipFree(c->d_eb_fresh);
+	if (c->h_events)
+		(void)hipHostFree(c->h_events);
+	if (c->h_eb)
+		(void)hipHostFree(c->h_eb);
+	if (c->copy)
+		(void)hipStreamDestroy(c->copy);
 	(void)hipFree(c->d_stage);
-	for (auto &e : c->ev)
-		if (e)
-			(void)hipEventDestroy(e);
-	for (auto &e : c->tev)
-		if (e)
-			(void)hipEventDestroy(e);
 	if (c->ev_fork)
 		(void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join)
@@ -349,15 +369,27 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	}
 	ALLOC(c->d_tail[0], n * kTailBytes);
 	ALLOC(c->d_tail[1], n * kTailBytes);
-	ALLOC(c->d_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event));
-	ALLOC(c->d_eb, sizeof(EventBuf));
+	for (int k = 0; k < 2; k++) {
+		ALLOC(c->d_events[k], (size_t)cfg->max_events * sizeof(tfrec_amd_event));
+		ALLOC(c->d_eb[k], sizeof(EventBuf));
+	}
+	ALLOC(c->d_eb_fresh, sizeof(EventBuf));
 #undef ALLOC
+	if (rc == TFREC_AMD_OK &&
+	    (hipHostMalloc((void **)&c->h_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
+	     hipHostMalloc((void **)&c->h_eb, sizeof(EventBuf), hipHostMallocDefault) != hipSuccess))
+		rc = TFREC_AMD_E_NOMEM;
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb = { 0u, (uint32_t)cfg->max_events, 0ull };
 		if (hipMemset(c->d_tail[0], 0x80, n * kTailBytes) != hipSuccess ||
 		    hipMemset(c->d_tail[1], 0x80, n * kTailBytes) != hipSuccess ||
-		    hipMemcpy(c->d_eb, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess)
+		    hipMemcpy(c->d_eb[0], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(c->d_eb[1], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
+		    hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && !(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
@@ -367,13 +399,15 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING)) {
-		for (auto &e : c->ev)
-			if (hipEventCreate(&e) != hipSuccess)
-				rc = TFREC_AMD_E_HIP;
-		if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS))
-			for (auto &e : c->tev)
+		for (int k = 0; k < 2; k++) {
+			for (auto &e : c->ev[k])
 				if (hipEventCreate(&e) != hipSuccess)
 					rc = TFREC_AMD_E_HIP;
+			if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS))
+				for (auto &e : c->tev[k])
+					if (hipEventCreate(&e) != hipSuccess)
+						rc = TFREC_AMD_E_HIP;
+		}
 	}
 	for (int a = 0; a < c->launch.n_active; a++)
 		c->whb_active = c->whb_active || c->launch.params[a].kind == 2;
@@ -394,31 +428,39 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 		snprintf(g_err, sizeof(g_err), "IQ base and stream stride must be 16-byte aligned and >= one stream");
 		return TFREC_AMD_E_INVAL;
 	}
+	if (c->inflight >= 2) {
+		snprintf(g_err, sizeof(g_err), "two submits are waiting to be drained: call tfrec_amd_drain_events first");
+		return TFREC_AMD_E_STATE;
+	}
 	HIPCHK(hipSetDevice(c->cfg.device));
 	hipStream_t st = (hipStream_t)hip_stream;
 	const bool timing = (c->cfg.flags & TFREC_AMD_F_TIMING) != 0;
+	const int set = (c->head + c->inflight) & 1;  // this submit's event buffers and timing events
+	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf), hipMemcpyDeviceToDevice, st));
 	if (timing)
-		HIPCHK(hipEventRecord(c->ev[0], st));
+		HIPCHK(hipEventRecord(c->ev[set][0], st));
 	HIPCHK(launch_frontend(st, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
 			       c->d_tail[c->tail_sel ^ 1], c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev,
-			       c->dec_stride, c->d_eb, c->cfg.thresh ? c->cfg.thresh : 500, c->taps));
+			       c->dec_stride, c->d_eb[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps));
 	if (c->d_fsk)  // auto threshold: per-block thresholds rewrite the trigger mask (fm_demod.cpp:58-73)
 		HIPCHK(launch_threshold(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
 					c->d_fsk, c->wmax));
 	if (timing)
-		HIPCHK(hipEventRecord(c->ev[1], st));
+		HIPCHK(hipEventRecord(c->ev[set][1], st));
 	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)
 		HIPCHK(launch_chains(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
-				     c->sample_base, c->launch, c->d_events, c->d_eb, c->cfg.flags));
+				     c->sample_base, c->launch, c->d_events[set], c->d_eb[set], c->cfg.flags));
 	else
 		HIPCHK(launch_pipeline(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev, c->dec_stride,
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16, c->d_dev32,
-				       c->d_events, c->d_eb, c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
-				       (timing && c->tev[0]) ? c->tev : nullptr));
+				       c->d_events[set], c->d_eb[set], c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
+				       (timing && c->tev[set][0]) ? c->tev[set] : nullptr));
 	if (timing) {
-		HIPCHK(hipEventRecord(c->ev[2], st));
+		HIPCHK(hipEventRecord(c->ev[set][2], st));
 		c->timed = true;
 	}
+	HIPCHK(hipEventRecord(c->done[set], st));
+	c->inflight++;
 	c->tail_sel ^= 1;
 	c->sample_base += (long long)n_blocks * kBlockDec;
 	c->last_blocks = n_blocks;
@@ -463,11 +505,14 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 {
 	if (!c || !n)
 		return TFREC_AMD_E_INVAL;
-	int rc = tfrec_amd_sync(c);
-	if (rc)
-		return rc;
-	EventBuf eb;
-	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
+	*n = 0;
+	if (c->inflight == 0)
+		return TFREC_AMD_OK;
+	HIPCHK(hipSetDevice(c->cfg.device));
+	HIPCHK(hipEventSynchronize(c->done[c->head]));  // the oldest submit not yet drained
+	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->copy));
+	HIPCHK(hipStreamSynchronize(c->copy));
+	const EventBuf eb = *c->h_eb;
 	*n = (int)std::min(eb.count, eb.capacity);
 	return eb.count > eb.capacity ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
 }
@@ -477,25 +522,37 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	if (!c || !n_out || cap < 0 || (cap > 0 && !out))
 		return TFREC_AMD_E_INVAL;
 	*n_out = 0;
-	int rc = tfrec_amd_sync(c);
-	if (rc)
-		return rc;
-	EventBuf eb;
-	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
+	if (c->inflight == 0)
+		return TFREC_AMD_OK;
+	HIPCHK(hipSetDevice(c->cfg.device));
+	const int set = c->head;  // the oldest submit not yet drained; a younger one may still be running
+	HIPCHK(hipEventSynchronize(c->done[set]));
+	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->copy));
+	HIPCHK(hipStreamSynchronize(c->copy));
+	const EventBuf eb = *c->h_eb;
 	const uint32_t have = std::min(eb.count, eb.capacity);
 	bool overflow = eb.count > eb.capacity;
-	if (c->win.overflow) {
+	if (have) {
+		HIPCHK(hipMemcpyAsync(c->h_events, c->d_events[set], (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost,
+				      c->copy));
+		HIPCHK(hipStreamSynchronize(c->copy));
+	}
+	c->head ^= 1;
+	c->inflight--;
+	c->last_drained = set;
+	c->uncertain_total += eb.uncertain;
+	if (c->win.overflow && c->inflight == 0) {
 		int32_t wov = 0;
-		HIPCHK(hipMemcpy(&wov, c->win.overflow, 4, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpyAsync(c->h_eb, c->win.overflow, 4, hipMemcpyDeviceToHost, c->copy));
+		HIPCHK(hipStreamSynchronize(c->copy));
+		memcpy(&wov, c->h_eb, 4);
 		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
 			snprintf(g_err, sizeof(g_err), "window table overflow");
 			return TFREC_AMD_E_STATE;
 		}
 	}
-	std::vector<tfrec_amd_event> tmp(have);
-	if (have)
-		HIPCHK(hipMemcpy(tmp.data(), c->d_events, (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost));
-	std::sort(tmp.begin(), tmp.end(), [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
+	tfrec_amd_event *tmp = c->h_events;
+	std::sort(tmp, tmp + have, [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
 		if (a.stream != b.stream)
 			return a.stream < b.stream;
 		if (a.slot != b.slot)
@@ -508,11 +565,8 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 		overflow = true;
 	}
 	if (ncopy)
-		memcpy(out, tmp.data(), (size_t)ncopy * sizeof(tfrec_amd_event));
+		memcpy(out, tmp, (size_t)ncopy * sizeof(tfrec_amd_event));
 	*n_out = (int)ncopy;
-	c->uncertain_total += eb.uncertain;
-	EventBuf fresh = { 0u, (uint32_t)c->cfg.max_events, 0ull };
-	HIPCHK(hipMemcpy(c->d_eb, &fresh, sizeof(fresh), hipMemcpyHostToDevice));
 	return overflow ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
 }
 
@@ -534,9 +588,12 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 	int rc = tfrec_amd_sync(c);
 	if (rc)
 		return rc;
-	EventBuf eb;
-	HIPCHK(hipMemcpy(&eb, c->d_eb, sizeof(eb), hipMemcpyDeviceToHost));
-	*n = c->uncertain_total + eb.uncertain;
+	*n = c->uncertain_total;
+	for (int k = 0; k < c->inflight; k++) {  // submits not drained yet
+		EventBuf eb;
+		HIPCHK(hipMemcpy(&eb, c->d_eb[(c->head + k) & 1], sizeof(eb), hipMemcpyDeviceToHost));
+		*n += eb.uncertain;
+	}
 	return TFREC_AMD_OK;
 }
 
@@ -563,19 +620,22 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 		return TFREC_AMD_E_INVAL;
 	if (!c->timed)
 		return TFREC_AMD_E_STATE;
-	HIPCHK(hipEventSynchronize(c->ev[2]));
-	HIPCHK(hipEventElapsedTime(&out->frontend_ms, c->ev[0], c->ev[1]));
-	HIPCHK(hipEventElapsedTime(&out->chains_ms, c->ev[1], c->ev[2]));
-	HIPCHK(hipEventElapsedTime(&out->total_ms, c->ev[0], c->ev[2]));
+	// the most recently drained submit; before the first drain: the oldest one in flight
+	const int set = c->last_drained >= 0 ? c->last_drained : c->head;
+	hipEvent_t *ev = c->ev[set], *tev = c->tev[set];
+	HIPCHK(hipEventSynchronize(ev[2]));
+	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[1]));
+	HIPCHK(hipEventElapsedTime(&out->chains_ms, ev[1], ev[2]));
+	HIPCHK(hipEventElapsedTime(&out->total_ms, ev[0], ev[2]));
 	out->windows_ms = out->spec_biquad_ms = out->fix_biquad_ms = out->slicer_ms = out->commit_ms = out->whb_ms = 0;
-	if (c->tev[0]) {
-		HIPCHK(hipEventElapsedTime(&out->windows_ms, c->tev[0], c->tev[1]));
-		HIPCHK(hipEventElapsedTime(&out->spec_biquad_ms, c->tev[1], c->tev[2]));
-		HIPCHK(hipEventElapsedTime(&out->fix_biquad_ms, c->tev[2], c->tev[3]));
-		HIPCHK(hipEventElapsedTime(&out->slicer_ms, c->tev[3], c->tev[4]));
-		HIPCHK(hipEventElapsedTime(&out->commit_ms, c->tev[4], c->tev[5]));
+	if (tev[0]) {
+		HIPCHK(hipEventElapsedTime(&out->windows_ms, tev[0], tev[1]));
+		HIPCHK(hipEventElapsedTime(&out->spec_biquad_ms, tev[1], tev[2]));
+		HIPCHK(hipEventElapsedTime(&out->fix_biquad_ms, tev[2], tev[3]));
+		HIPCHK(hipEventElapsedTime(&out->slicer_ms, tev[3], tev[4]));
+		HIPCHK(hipEventElapsedTime(&out->commit_ms, tev[4], tev[5]));
 		if (c->whb_active)
-			HIPCHK(hipEventElapsedTime(&out->whb_ms, c->tev[6], c->tev[7]));
+			HIPCHK(hipEventElapsedTime(&out->whb_ms, tev[6], tev[7]));
 	}
 	return TFREC_AMD_OK;
 }
