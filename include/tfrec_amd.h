@@ -103,9 +103,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out);
 int tfrec_amd_destroy(tfrec_amd_ctx *ctx);
 
 /* Process n_blocks 65536-byte blocks of every stream.  Stream s starts at d_iq + s*stream_stride_bytes
- * (device memory, u8 interleaved I,Q as the reference's -S dump files, sdr.cpp:233-234).  Asynchronous
- * on hip_stream (a hipStream_t, NULL = default stream); all demodulator/decoder state carries over to
- * the next submit exactly as it carries from block to block in the reference. */
+ * (device memory, u8 interleaved I,Q as the reference's -S dump files, sdr.cpp:233-234).  Asynchronous:
+ * the work is ordered after what is already queued on hip_stream (a hipStream_t, NULL = default stream) -- the
+ * producer of d_iq -- and runs on the context's own streams; d_iq must stay valid until the submit has been
+ * drained (or tfrec_amd_sync returned).  All demodulator/decoder state carries over to the next submit exactly as
+ * it carries from block to block in the reference. */
 int tfrec_amd_submit_device(tfrec_amd_ctx *ctx, const void *d_iq, size_t stream_stride_bytes, int n_blocks,
 			    void *hip_stream);
 /* Same with host memory: stages the batch through an internal device buffer (H2D copy included). */

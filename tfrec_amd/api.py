@@ -158,7 +158,7 @@ class Receiver:
         _check(self.L, self.L.tfrec_amd_create(C.byref(self.cfg), C.byref(self.h)))
         self.n_streams = n_streams
         self.max_events = max_events
-        self._keep = None
+        self._keep = ()
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -190,7 +190,7 @@ class Receiver:
         assert iq.stride(1) == 1
         nb = iq.shape[1] // BLOCK_BYTES if n_blocks is None else n_blocks
         st = torch.cuda.current_stream(iq.device) if stream is None else stream
-        self._keep = iq  # keep the buffer alive until the next submit/drain
+        self._keep = (getattr(self, "_keep", ()) + (iq,))[-2:]  # inputs stay alive while their submit may be in flight
         _check(self.L, self.L.tfrec_amd_submit_device(self.h, C.c_void_p(iq.data_ptr()), iq.stride(0), nb,
                                                       C.c_void_p(st.cuda_stream)))
         return nb

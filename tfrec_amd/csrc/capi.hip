@@ -46,11 +46,19 @@ struct tfrec_amd_ctx {
 	tfrec_amd_config cfg;
 	ChainLaunch launch;
 	FrontTaps taps;
-	uint32_t *d_dec = nullptr;
+	// front-end outputs, double-buffered like the event buffers: the front end of submit k+1 (its own stream)
+	// runs beside the demodulator chains of submit k
+	uint32_t *d_dec[2] = { nullptr, nullptr };
 	size_t dec_stride = 0;  // uint32 units
-	unsigned long long *d_mask = nullptr;
+	unsigned long long *d_mask[2] = { nullptr, nullptr };
 	size_t mask_stride = 0;
-	int16_t *d_fmdev = nullptr;  // [n_streams][m_max] fm_dev of every decimated sample
+	int16_t *d_fmdev[2] = { nullptr, nullptr };  // [n_streams][m_max] fm_dev of every decimated sample
+	// Few streams on purpose: HIP multiplexes streams onto 4 hardware queues, and two streams that share a queue
+	// serialise (measured: the WHB chain stopped overlapping the TFA chains with a fifth stream in the process).
+	hipStream_t fs = nullptr;                     // front-end stream (+ the drain's device-to-host copies)
+	hipStream_t cs = nullptr;                     // chains stream (the caller's stream only orders the input)
+	hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_front[2] = { nullptr, nullptr };
+	int last_set = 0;
 	int16_t *d_ld16 = nullptr;   // [chains][m_max] tfa2-family biquad outputs
 	int32_t *d_dev32 = nullptr;  // [n_streams][m_max] WHB stage-1 outputs
 	WinTables win = {};
@@ -66,7 +74,6 @@ struct tfrec_amd_ctx {
 	tfrec_amd_event *h_events = nullptr;  // pinned staging for the drain
 	EventBuf *h_eb = nullptr;
 	hipEvent_t done[2] = { nullptr, nullptr };  // end of the submit that owns the set
-	hipStream_t copy = nullptr;           // non-blocking stream of the drain's device-to-host copies
 	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..2)
 	int last_drained = -1;
 	uint8_t *d_stage = nullptr;
@@ -164,9 +171,19 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	for (int a = 0; a < kNSlots; a++)
 		if (c->launch.states[a])
 			(void)hipFree(c->launch.states[a]);
-	(void)hipFree(c->d_dec);
-	(void)hipFree(c->d_mask);
-	(void)hipFree(c->d_fmdev);
+	for (int k = 0; k < 2; k++) {
+		(void)hipFree(c->d_dec[k]);
+		(void)hipFree(c->d_mask[k]);
+		(void)hipFree(c->d_fmdev[k]);
+		if (c->ev_in[k])
+			(void)hipEventDestroy(c->ev_in[k]);
+		if (c->ev_front[k])
+			(void)hipEventDestroy(c->ev_front[k]);
+	}
+	if (c->fs)
+		(void)hipStreamDestroy(c->fs);
+	if (c->cs)
+		(void)hipStreamDestroy(c->cs);
 	(void)hipFree(c->d_ld16);
 	(void)hipFree(c->d_dev32);
 	(void)hipFree(c->win_block);
@@ -190,8 +207,6 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipHostFree(c->h_events);
 	if (c->h_eb)
 		(void)hipHostFree(c->h_eb);
-	if (c->copy)
-		(void)hipStreamDestroy(c->copy);
 	(void)hipFree(c->d_stage);
 	if (c->ev_fork)
 		(void)hipEventDestroy(c->ev_fork);
@@ -297,8 +312,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	}
 	c->dec_stride = m_max;
 	c->mask_stride = m_max / 64;
-	ALLOC(c->d_dec, n * c->dec_stride * sizeof(uint32_t) + 256);  // + slack: K3 loads whole 32-sample chunks at window tails
-	ALLOC(c->d_mask, n * c->mask_stride * sizeof(unsigned long long));
+	for (int k = 0; k < 2; k++) {
+		ALLOC(c->d_dec[k], n * c->dec_stride * sizeof(uint32_t) + 256);  // + slack: K3 loads whole 32-sample chunks at window tails
+		ALLOC(c->d_mask[k], n * c->mask_stride * sizeof(unsigned long long));
+	}
 	for (int a = 0; a < c->launch.n_active; a++)
 		c->wmax = std::max(c->wmax, (int)c->launch.params[a].window);
 	if (cfg->thresh == 0) {  // fm_demod.cpp:23-27: 0 selects the adaptive mode starting at 500
@@ -309,7 +326,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 				rc = TFREC_AMD_E_HIP;
 		}
 	}
-	ALLOC(c->d_fmdev, n * m_max * sizeof(int16_t) + 256);  // + slack: K3 reads whole dwords past an odd tail
+	for (int k = 0; k < 2; k++)
+		ALLOC(c->d_fmdev[k], n * m_max * sizeof(int16_t) + 256);  // + slack: K3 reads whole dwords past an odd tail
 	if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
 		// window-parallel pipeline buffers (chains2.hip)
 		const size_t chains = (size_t)c->launch.n_active * n;
@@ -379,6 +397,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	    (hipHostMalloc((void **)&c->h_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
 	     hipHostMalloc((void **)&c->h_eb, sizeof(EventBuf), hipHostMallocDefault) != hipSuccess))
 		rc = TFREC_AMD_E_NOMEM;
+	// The latency-bound chains get the high-priority queues; the throughput-bound front end of the NEXT submit,
+	// which runs beside them, fills what they leave free.
+	int prio_lo = 0, prio_hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb = { 0u, (uint32_t)cfg->max_events, 0ull };
@@ -387,13 +409,18 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    hipMemcpy(c->d_eb[0], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(c->d_eb[1], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
-		    hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess ||
+		    hipStreamCreateWithPriority(&c->fs, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+		    hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->ev_in[0], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->ev_in[1], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->ev_front[0], hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->ev_front[1], hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && !(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
-		if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+		if (hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
@@ -433,27 +460,34 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 		return TFREC_AMD_E_STATE;
 	}
 	HIPCHK(hipSetDevice(c->cfg.device));
-	hipStream_t st = (hipStream_t)hip_stream;
 	const bool timing = (c->cfg.flags & TFREC_AMD_F_TIMING) != 0;
 	const int set = (c->head + c->inflight) & 1;  // this submit's event buffers and timing events
-	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf), hipMemcpyDeviceToDevice, st));
+	// Front end on its own stream: it starts when the caller's stream has produced the input, and may overlap the
+	// chains of the previous submit (different buffer set; the set's previous user was drained, see the FIFO rule)
+	hipStream_t fs = c->fs;
+	HIPCHK(hipEventRecord(c->ev_in[set], (hipStream_t)hip_stream));
+	hipStream_t st = c->cs;  // the chains run on an internal stream: nothing of ours is queued on the caller's
+	HIPCHK(hipStreamWaitEvent(fs, c->ev_in[set], 0));
+	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf), hipMemcpyDeviceToDevice, fs));
 	if (timing)
-		HIPCHK(hipEventRecord(c->ev[set][0], st));
-	HIPCHK(launch_frontend(st, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
-			       c->d_tail[c->tail_sel ^ 1], c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev,
-			       c->dec_stride, c->d_eb[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps));
+		HIPCHK(hipEventRecord(c->ev[set][0], fs));
+	HIPCHK(launch_frontend(fs, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
+			       c->d_tail[c->tail_sel ^ 1], c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride,
+			       c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps));
 	if (c->d_fsk)  // auto threshold: per-block thresholds rewrite the trigger mask (fm_demod.cpp:58-73)
-		HIPCHK(launch_threshold(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
-					c->d_fsk, c->wmax));
+		HIPCHK(launch_threshold(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams,
+					n_blocks, c->d_fsk, c->wmax));
 	if (timing)
-		HIPCHK(hipEventRecord(c->ev[set][1], st));
+		HIPCHK(hipEventRecord(c->ev[set][1], fs));
+	HIPCHK(hipEventRecord(c->ev_front[set], fs));
+	HIPCHK(hipStreamWaitEvent(st, c->ev_front[set], 0));
 	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)
-		HIPCHK(launch_chains(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->cfg.n_streams, n_blocks,
+		HIPCHK(launch_chains(st, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams, n_blocks,
 				     c->sample_base, c->launch, c->d_events[set], c->d_eb[set], c->cfg.flags));
 	else
-		HIPCHK(launch_pipeline(st, c->d_dec, c->dec_stride, c->d_mask, c->mask_stride, c->d_fmdev, c->dec_stride,
-				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16, c->d_dev32,
-				       c->d_events[set], c->d_eb[set], c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
+		HIPCHK(launch_pipeline(st, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set],
+				       c->dec_stride, c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16,
+				       c->d_dev32, c->d_events[set], c->d_eb[set], c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
 				       (timing && c->tev[set][0]) ? c->tev[set] : nullptr));
 	if (timing) {
 		HIPCHK(hipEventRecord(c->ev[set][2], st));
@@ -461,6 +495,7 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	}
 	HIPCHK(hipEventRecord(c->done[set], st));
 	c->inflight++;
+	c->last_set = set;
 	c->tail_sel ^= 1;
 	c->sample_base += (long long)n_blocks * kBlockDec;
 	c->last_blocks = n_blocks;
@@ -510,8 +545,8 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
 	HIPCHK(hipEventSynchronize(c->done[c->head]));  // the oldest submit not yet drained
-	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->copy));
-	HIPCHK(hipStreamSynchronize(c->copy));
+	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->fs));
+	HIPCHK(hipStreamSynchronize(c->fs));
 	const EventBuf eb = *c->h_eb;
 	*n = (int)std::min(eb.count, eb.capacity);
 	return eb.count > eb.capacity ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
@@ -527,15 +562,15 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const int set = c->head;  // the oldest submit not yet drained; a younger one may still be running
 	HIPCHK(hipEventSynchronize(c->done[set]));
-	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->copy));
-	HIPCHK(hipStreamSynchronize(c->copy));
+	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->fs));
+	HIPCHK(hipStreamSynchronize(c->fs));
 	const EventBuf eb = *c->h_eb;
 	const uint32_t have = std::min(eb.count, eb.capacity);
 	bool overflow = eb.count > eb.capacity;
 	if (have) {
 		HIPCHK(hipMemcpyAsync(c->h_events, c->d_events[set], (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost,
-				      c->copy));
-		HIPCHK(hipStreamSynchronize(c->copy));
+				      c->fs));
+		HIPCHK(hipStreamSynchronize(c->fs));
 	}
 	c->head ^= 1;
 	c->inflight--;
@@ -543,8 +578,8 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	c->uncertain_total += eb.uncertain;
 	if (c->win.overflow && c->inflight == 0) {
 		int32_t wov = 0;
-		HIPCHK(hipMemcpyAsync(c->h_eb, c->win.overflow, 4, hipMemcpyDeviceToHost, c->copy));
-		HIPCHK(hipStreamSynchronize(c->copy));
+		HIPCHK(hipMemcpyAsync(c->h_eb, c->win.overflow, 4, hipMemcpyDeviceToHost, c->fs));
+		HIPCHK(hipStreamSynchronize(c->fs));
 		memcpy(&wov, c->h_eb, 4);
 		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
 			snprintf(g_err, sizeof(g_err), "window table overflow");
@@ -577,7 +612,8 @@ int tfrec_amd_read_decimated(tfrec_amd_ctx *c, int stream, int16_t *out, size_t 
 	int rc = tfrec_amd_sync(c);
 	if (rc)
 		return rc;
-	HIPCHK(hipMemcpy(out, c->d_dec + (size_t)stream * c->dec_stride, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out, c->d_dec[c->last_set] + (size_t)stream * c->dec_stride, n_pairs * sizeof(uint32_t),
+			 hipMemcpyDeviceToHost));
 	return TFREC_AMD_OK;
 }
 
