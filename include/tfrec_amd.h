@@ -90,8 +90,10 @@ typedef struct {
 	float frontend_ms; /* u8->s16 + 2-stage decimating FIR + trigger mask + FM discriminator kernel */
 	float chains_ms;   /* all demodulator/decoder kernels together (end of front end -> end of last kernel) */
 	float total_ms;    /* first kernel start to last kernel end */
-	/* individual kernels of the window-parallel pipeline (0 when not run); whb_ms runs beside slicer+commit */
-	float windows_ms, spec_biquad_ms, fix_biquad_ms, slicer_ms, commit_ms, whb_ms;
+	/* individual kernels of the window-parallel pipeline (0 when not run).  TFA chains: */
+	float windows_ms, spec_biquad_ms, repair_biquad_ms, fix_biquad_ms, slicer_ms, coop_slicer_ms, decode_ms, commit_ms;
+	/* the WHB chain runs beside them on its own stream: its three biquad kernels together, then stage 2 */
+	float whb_biquad_ms, whb_demod_ms, whb_decode_ms, whb_commit_ms;
 } tfrec_amd_timings;
 
 const char *tfrec_amd_version(void);

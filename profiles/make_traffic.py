@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel LAUNCH from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace domains).
+usage: make_traffic.py <fetch_dir> <write_dir> <out.json> <streams> <blocks> <types>
+hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts half of the bytes of a 16 B/lane stream
+(MI355X_MICROARCH.md, HBM section); check: frontend_kernel reads 2*1.62 GB = 3.3 GB vs 3.22 GB of input."""
+import collections, csv, glob, json, sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
+    acc = collections.defaultdict(list)
+    per_dispatch = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != counter:
+            continue
+        per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].replace("tfrec::", "")
+    for d_id, v in per_dispatch.items():
+        acc[names[d_id]].append(v)
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+fetch, n = per_kernel(sys.argv[1], "FETCH_SIZE")
+write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"note": __doc__.strip().split("\n", 2)[2], "streams": int(sys.argv[4]), "blocks": int(sys.argv[5]),
+       "types": int(sys.argv[6]), "kernels": {}}
+for k in sorted(fetch):
+    if k.startswith("__"):
+        continue
+    out["kernels"][k] = {"fetch_size_kb_raw": round(fetch[k], 1), "write_size_kb_raw": round(write.get(k, 0.0), 1),
+                         "hbm_bytes": int((2 * fetch[k] + write.get(k, 0.0)) * 1024), "dispatches_profiled": n[k]}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))

@@ -84,8 +84,7 @@ struct tfrec_amd_ctx {
 	hipEvent_t ev[2][3] = { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } };
 	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	hipEvent_t tev[2][8] = { { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr },
-				 { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr } };
+	hipEvent_t tev[2][16] = {};
 	bool whb_active = false;
 	bool timed = false;
 	unsigned long long uncertain_total = 0;
@@ -663,15 +662,20 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[1]));
 	HIPCHK(hipEventElapsedTime(&out->chains_ms, ev[1], ev[2]));
 	HIPCHK(hipEventElapsedTime(&out->total_ms, ev[0], ev[2]));
-	out->windows_ms = out->spec_biquad_ms = out->fix_biquad_ms = out->slicer_ms = out->commit_ms = out->whb_ms = 0;
+	out->windows_ms = out->spec_biquad_ms = out->repair_biquad_ms = out->fix_biquad_ms = out->slicer_ms = 0;
+	out->coop_slicer_ms = out->decode_ms = out->commit_ms = 0;
+	out->whb_biquad_ms = out->whb_demod_ms = out->whb_decode_ms = out->whb_commit_ms = 0;
 	if (tev[0]) {
-		HIPCHK(hipEventElapsedTime(&out->windows_ms, tev[0], tev[1]));
-		HIPCHK(hipEventElapsedTime(&out->spec_biquad_ms, tev[1], tev[2]));
-		HIPCHK(hipEventElapsedTime(&out->fix_biquad_ms, tev[2], tev[3]));
-		HIPCHK(hipEventElapsedTime(&out->slicer_ms, tev[3], tev[4]));
-		HIPCHK(hipEventElapsedTime(&out->commit_ms, tev[4], tev[5]));
-		if (c->whb_active)
-			HIPCHK(hipEventElapsedTime(&out->whb_ms, tev[6], tev[7]));
+		float *main_ms[8] = { &out->windows_ms, &out->spec_biquad_ms, &out->repair_biquad_ms, &out->fix_biquad_ms,
+				      &out->slicer_ms,  &out->coop_slicer_ms, &out->decode_ms,        &out->commit_ms };
+		for (int k = 0; k < 8; k++)
+			HIPCHK(hipEventElapsedTime(main_ms[k], tev[k], tev[k + 1]));
+		if (c->whb_active) {
+			HIPCHK(hipEventElapsedTime(&out->whb_biquad_ms, tev[9], tev[12]));
+			HIPCHK(hipEventElapsedTime(&out->whb_demod_ms, tev[12], tev[13]));
+			HIPCHK(hipEventElapsedTime(&out->whb_decode_ms, tev[13], tev[14]));
+			HIPCHK(hipEventElapsedTime(&out->whb_commit_ms, tev[14], tev[15]));
+		}
 	}
 	return TFREC_AMD_OK;
 }

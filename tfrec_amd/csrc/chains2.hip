@@ -1349,11 +1349,9 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 
 __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
-							 ChainLaunch L, WinTables T, int kinds)
+							 ChainLaunch L, WinTables T)
 {
 	__shared__ int lds_m[64];
-	if (!((kinds >> blockIdx.y) & 1))
-		return;  // (experiments: TFREC_AMD_COOP_KINDS)
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int kind = blockIdx.y;
@@ -2147,8 +2145,9 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
 			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev)
 {
-	// tev (optional, 9 events): 0 start, 1 after windows, 2 after spec, 3 after fix, 4 after slicer, 5 after commit,
-	// 6/7 around whb (on its own stream)
+	// tev (optional, 16 events), one interval per kernel -- main stream: 0 | windows | 1 | spec | 2 | repair | 3 | fix | 4
+	// | slicer | 5 | coop_slicer | 6 | decode | 7 | commit | 8; WHB stream: 9 | spec | 10 | repair | 11 | fix | 12 |
+	// whb_demod | 13 | whb_decode | 14 | whb_commit | 15
 	auto mark = [&](int k, hipStream_t s_) {
 		if (tev)
 			(void)hipEventRecord(tev[k], s_);
@@ -2178,8 +2177,8 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   long_window);
 	mark(1, st);
 	// Two independent kernel chains after the window scan (they touch disjoint state):
-	//   aux stream : WHB   spec_biquad -> fix_biquad -> whb_demod_kernel -> whb_commit_kernel
-	//   main stream: TFA   spec_biquad -> fix_biquad -> slicer_kernel -> commit_kernel
+	//   aux stream : WHB   spec -> repair -> fix (biquad)  -> whb_demod -> whb_decode -> whb_commit
+	//   main stream: TFA   spec -> repair -> fix (biquads) -> slicer -> coop_slicer -> decode -> commit
 	bool has_whb = false, has_tfa2 = false;
 	for (int a = 0; a < L.n_active; a++) {
 		has_whb = has_whb || L.params[a].kind == 2;
@@ -2194,47 +2193,55 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			forked = true;
 			ws = aux;
 		}
+		mark(9, ws);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 0);
+		mark(10, ws);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 1);
+		mark(11, ws);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 2);
-		mark(6, ws);
+		mark(12, ws);
 		for (int a = 0; a < L.n_active; a++)
 			if (L.params[a].kind == 2) {
 				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, 0, ws, dec, dec_stride, dev32,
 						   n_streams, n_blocks, L, a, T);
+				mark(13, ws);
 				hipLaunchKernelGGL(whb_decode_kernel, dim3(std::max(1, dec_blocks / 4)), block, 0, ws, n_streams, L, a, T);
+				mark(14, ws);
 				hipLaunchKernelGGL(whb_commit_kernel, dim3((n_streams + 63) / 64), block, 0, ws, dec, dec_stride, n_streams,
 						   n_blocks, sample_base, L, a, T, events, eb, flags);
+				mark(15, ws);
 			}
-		mark(7, ws);
 		if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
 			return e;
 	}
 	if (has_tfa2) {
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);
+		mark(2, st);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
-		mark(2, st);
+		mark(3, st);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 1);
-	} else
+	} else {
 		mark(2, st);
-	mark(3, st);
+		mark(3, st);
+	}
+	mark(4, st);
 	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 48));
 	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
 			   lanes_win, head_chunks);
-	if (!env_int("TFREC_AMD_NO_COOP", 0))
-		hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L,
-				   T, env_int("TFREC_AMD_COOP_KINDS", 3));
-	mark(4, st);
+	mark(5, st);
+	hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T);
+	mark(6, st);
 	hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks, 2), block, 0, st, n_streams, L, T);
+	mark(7, st);
 	hipLaunchKernelGGL(commit_kernel, grid, block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
 			   events, eb, flags, lanes_chain);
-	mark(5, st);
+	mark(8, st);
 	if (forked && (e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess)
 		return e;
 	return hipGetLastError();
