@@ -18,7 +18,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
-			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev);
+			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev, hipStream_t t1, hipEvent_t ev_join1);
 hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stride, unsigned long long *mask,
 			    size_t mask_stride, int n_streams, int n_blocks, FskState *fsk, int wmax);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
@@ -84,7 +84,9 @@ struct tfrec_amd_ctx {
 	hipEvent_t ev[2][3] = { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } };
 	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	hipEvent_t tev[2][16] = {};
+	hipEvent_t tev[2][21] = {};
+	hipStream_t t1 = nullptr;  // TFA_1 slicer chain (needs no biquad stage: runs beside the TFA_2-family biquads)
+	hipEvent_t ev_join1 = nullptr;
 	bool whb_active = false;
 	bool timed = false;
 	unsigned long long uncertain_total = 0;
@@ -213,6 +215,10 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipEventDestroy(c->ev_join);
 	if (c->aux)
 		(void)hipStreamDestroy(c->aux);
+	if (c->t1)
+		(void)hipStreamDestroy(c->t1);
+	if (c->ev_join1)
+		(void)hipEventDestroy(c->ev_join1);
 	delete c;
 	return TFREC_AMD_OK;
 }
@@ -419,6 +425,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && !(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
+		if (getenv("TFREC_AMD_NO_T1") == nullptr &&
+		    (hipStreamCreateWithPriority(&c->t1, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+		     hipEventCreateWithFlags(&c->ev_join1, hipEventDisableTiming) != hipSuccess))
+			rc = TFREC_AMD_E_HIP;
 		if (hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
@@ -487,7 +497,7 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 		HIPCHK(launch_pipeline(st, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set],
 				       c->dec_stride, c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16,
 				       c->d_dev32, c->d_events[set], c->d_eb[set], c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
-				       (timing && c->tev[set][0]) ? c->tev[set] : nullptr));
+				       (timing && c->tev[set][0]) ? c->tev[set] : nullptr, c->t1, c->ev_join1));
 	if (timing) {
 		HIPCHK(hipEventRecord(c->ev[set][2], st));
 		c->timed = true;
@@ -665,11 +675,15 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	out->windows_ms = out->spec_biquad_ms = out->repair_biquad_ms = out->fix_biquad_ms = out->slicer_ms = 0;
 	out->coop_slicer_ms = out->decode_ms = out->commit_ms = 0;
 	out->whb_biquad_ms = out->whb_demod_ms = out->whb_decode_ms = out->whb_commit_ms = 0;
+	out->tfa1_slicer_ms = out->tfa1_coop_slicer_ms = out->tfa1_decode_commit_ms = 0;
 	if (tev[0]) {
 		float *main_ms[8] = { &out->windows_ms, &out->spec_biquad_ms, &out->repair_biquad_ms, &out->fix_biquad_ms,
 				      &out->slicer_ms,  &out->coop_slicer_ms, &out->decode_ms,        &out->commit_ms };
 		for (int k = 0; k < 8; k++)
 			HIPCHK(hipEventElapsedTime(main_ms[k], tev[k], tev[k + 1]));
+		HIPCHK(hipEventElapsedTime(&out->tfa1_slicer_ms, tev[16], tev[17]));
+		HIPCHK(hipEventElapsedTime(&out->tfa1_coop_slicer_ms, tev[17], tev[18]));
+		HIPCHK(hipEventElapsedTime(&out->tfa1_decode_commit_ms, tev[18], tev[20]));
 		if (c->whb_active) {
 			HIPCHK(hipEventElapsedTime(&out->whb_biquad_ms, tev[9], tev[12]));
 			HIPCHK(hipEventElapsedTime(&out->whb_demod_ms, tev[12], tev[13]));

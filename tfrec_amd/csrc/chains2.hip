@@ -996,7 +996,7 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 // for a whole wave) -- the rest, and the long TFA_1 windows, belong to coop_slicer_kernel.
 __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks, ChainLaunch L,
-						    WinTables T, int lanes, int head_chunks)
+						    WinTables T, int lanes, int head_chunks, int kind)
 {
 	__shared__ uint4 slot_lds[8 * 64];
 	uint4 *my_lds = slot_lds + threadIdx.x;
@@ -1004,7 +1004,6 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 		return;
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-	const int kind = blockIdx.y;
 	for (int q = 2 * kind + (kind == 0 ? 1 : 0); q < 2 * kind + 2; q++) {
 		const uint32_t count = T.queue[q].count;
 		const int head = (q & 1) == 0 ? head_chunks : 0;
@@ -1349,12 +1348,11 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 
 __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
-							 ChainLaunch L, WinTables T)
+							 ChainLaunch L, WinTables T, int kind)
 {
 	__shared__ int lds_m[64];
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-	const int kind = blockIdx.y;
 	const int q = 2 * kind;  // the long windows of this kind
 	const uint32_t count = T.queue[q].count;
 	for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {  // wave-uniform
@@ -1967,13 +1965,12 @@ __device__ __forceinline__ void decode_window(int c, int j, int n_streams, const
 		dst[q] = src[q];
 }
 
-__global__ __launch_bounds__(64) void decode_kernel(int n_streams, ChainLaunch L, WinTables T)
+__global__ __launch_bounds__(64) void decode_kernel(int n_streams, ChainLaunch L, WinTables T, int kind)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
 	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
-	const int kind = blockIdx.y;
 	for (int q = 2 * kind; q < 2 * kind + 2; q++) {  // long windows first
 		const uint32_t count = T.queue[q].count;
 		for (uint32_t idx = tid; idx < count; idx += nthreads) {
@@ -2119,7 +2116,7 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
 						    long long sample_base, ChainLaunch L, WinTables T,
 						    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
-						    int lanes)
+						    int lanes, int want_kind)
 {
 	__shared__ uint4 slot_lds[8 * 64];
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
@@ -2130,6 +2127,8 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 	if ((int)threadIdx.x >= lanes || s >= n_streams)
 		return;
 	const int kind = L.params[a].kind;
+	if (kind != want_kind)
+		return;
 	if (kind == 0)
 		commit_body<0>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
 			       my_rdata);
@@ -2143,9 +2142,9 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
-			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev)
+			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev, hipStream_t t1, hipEvent_t ev_join1)
 {
-	// tev (optional, 16 events), one interval per kernel -- main stream: 0 | windows | 1 | spec | 2 | repair | 3 | fix | 4
+	// tev (optional, 21 events; 16..20: the TFA_1 slicer chain, on stream t1 if given), one interval per kernel -- main stream: 0 | windows | 1 | spec | 2 | repair | 3 | fix | 4
 	// | slicer | 5 | coop_slicer | 6 | decode | 7 | commit | 8; WHB stream: 9 | spec | 10 | repair | 11 | fix | 12 |
 	// whb_demod | 13 | whb_decode | 14 | whb_commit | 15
 	auto mark = [&](int k, hipStream_t s_) {
@@ -2184,7 +2183,14 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		has_whb = has_whb || L.params[a].kind == 2;
 		has_tfa2 = has_tfa2 || L.params[a].kind == 1;
 	}
-	bool forked = false;
+	bool forked = false, t1_forked = false, has_tfa1 = false;
+	for (int a = 0; a < L.n_active; a++)
+		has_tfa1 = has_tfa1 || L.params[a].kind == 0;
+	if (t1 && has_tfa1 && has_tfa2) {  // TFA_1 needs no biquad stage: its slicers start right after the window scan
+		if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(t1, ev_fork, 0)) != hipSuccess)
+			return e;
+		t1_forked = true;
+	}
 	if (has_whb) {
 		hipStream_t ws = st;
 		if (aux) {
@@ -2232,16 +2238,33 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	}
 	mark(4, st);
 	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 48));
-	hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
-			   lanes_win, head_chunks);
-	mark(5, st);
-	hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks, 2), block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, L, T);
-	mark(6, st);
-	hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks, 2), block, 0, st, n_streams, L, T);
-	mark(7, st);
-	hipLaunchKernelGGL(commit_kernel, grid, block, 0, st, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
-			   events, eb, flags, lanes_chain);
-	mark(8, st);
+	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
+	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
+		hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
+				   lanes_win, head_chunks, kind);
+		mark(m0 + 1, s_);
+		hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L,
+				   T, kind);
+		mark(m0 + 2, s_);
+		hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks), block, 0, s_, n_streams, L, T, kind);
+		mark(m0 + 3, s_);
+		hipLaunchKernelGGL(commit_kernel, grid, block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
+				   events, eb, flags, lanes_chain, kind);
+		mark(m0 + 4, s_);
+	};
+	if (t1_forked) {
+		mark(16, t1);
+		slicer_chain(0, t1, 16);  // marks 17..20
+		if ((e = hipEventRecord(ev_join1, t1)) != hipSuccess)
+			return e;
+	}
+	slicer_chain(1, st, 4);  // marks 5..8
+	if (!t1_forked) {  // no third stream: TFA_1 after the TFA_2 family
+		mark(16, st);
+		slicer_chain(0, st, 16);  // marks 17..20
+	}
+	if (t1_forked && (e = hipStreamWaitEvent(st, ev_join1, 0)) != hipSuccess)
+		return e;
 	if (forked && (e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess)
 		return e;
 	return hipGetLastError();
