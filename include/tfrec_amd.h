@@ -114,8 +114,14 @@ int tfrec_amd_destroy(tfrec_amd_ctx *ctx);
  * it carries from block to block in the reference. */
 int tfrec_amd_submit_device(tfrec_amd_ctx *ctx, const void *d_iq, size_t stream_stride_bytes, int n_blocks,
 			    void *hip_stream);
-/* Same with host memory: stages the batch through an internal device buffer (H2D copy included). */
+/* Same with host memory: stages the batch through an internal device buffer (H2D copy included).  With pinned
+ * memory (tfrec_amd_host_alloc) the copy is asynchronous and h_iq must stay untouched until the submit has been
+ * drained; together with the depth-2 FIFO below this is the double-buffered feeder of SURVEY row f1: read batch
+ * k+2 from disk while batch k+1 is copied/processed and batch k's events are dispatched. */
 int tfrec_amd_submit_host(tfrec_amd_ctx *ctx, const uint8_t *h_iq, size_t stream_stride_bytes, int n_blocks);
+/* Page-locked host memory for tfrec_amd_submit_host (NULL on failure). */
+void *tfrec_amd_host_alloc(size_t bytes);
+void tfrec_amd_host_free(void *p);
 
 /* Wait for submitted work. */
 int tfrec_amd_sync(tfrec_amd_ctx *ctx);

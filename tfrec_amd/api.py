@@ -76,7 +76,8 @@ EXPORTS = (
     "tfrec_amd_version", "tfrec_amd_strerror", "tfrec_amd_last_error", "tfrec_amd_create", "tfrec_amd_destroy",
     "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
-    "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats",
+    "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_host_alloc",
+    "tfrec_amd_host_free",
 )
 
 _lib = None

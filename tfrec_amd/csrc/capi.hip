@@ -76,8 +76,8 @@ struct tfrec_amd_ctx {
 	hipEvent_t done[2] = { nullptr, nullptr };  // end of the submit that owns the set
 	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..2)
 	int last_drained = -1;
-	uint8_t *d_stage = nullptr;
-	size_t stage_bytes = 0;
+	uint8_t *d_stage[2] = { nullptr, nullptr };  // tfrec_amd_submit_host: device staging, one per buffer set
+	size_t stage_bytes[2] = { 0, 0 };
 	long long sample_base = 0;
 	int last_blocks = 0;
 	hipStream_t last_stream = nullptr;
@@ -208,7 +208,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipHostFree(c->h_events);
 	if (c->h_eb)
 		(void)hipHostFree(c->h_eb);
-	(void)hipFree(c->d_stage);
+	(void)hipFree(c->d_stage[0]);
+	(void)hipFree(c->d_stage[1]);
 	if (c->ev_fork)
 		(void)hipEventDestroy(c->ev_fork);
 	if (c->ev_join)
@@ -455,7 +456,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	return TFREC_AMD_OK;
 }
 
-int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int n_blocks, void *hip_stream)
+// in_stream_is_fs: the input was produced on the front-end stream itself (staged host input): no event needed
+static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int n_blocks, void *hip_stream, bool input_on_fs)
 {
 	if (!c || !d_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
 		return TFREC_AMD_E_INVAL;
@@ -474,9 +476,11 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	// Front end on its own stream: it starts when the caller's stream has produced the input, and may overlap the
 	// chains of the previous submit (different buffer set; the set's previous user was drained, see the FIFO rule)
 	hipStream_t fs = c->fs;
-	HIPCHK(hipEventRecord(c->ev_in[set], (hipStream_t)hip_stream));
 	hipStream_t st = c->cs;  // the chains run on an internal stream: nothing of ours is queued on the caller's
-	HIPCHK(hipStreamWaitEvent(fs, c->ev_in[set], 0));
+	if (!input_on_fs) {
+		HIPCHK(hipEventRecord(c->ev_in[set], (hipStream_t)hip_stream));
+		HIPCHK(hipStreamWaitEvent(fs, c->ev_in[set], 0));
+	}
 	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf), hipMemcpyDeviceToDevice, fs));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][0], fs));
@@ -512,6 +516,11 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	return TFREC_AMD_OK;
 }
 
+int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int n_blocks, void *hip_stream)
+{
+	return submit_common(c, d_iq, stride, n_blocks, hip_stream, false);
+}
+
 int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks)
 {
 	if (!c || !h_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
@@ -519,21 +528,39 @@ int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, 
 	const size_t row = (size_t)n_blocks * TFREC_AMD_BLOCK_BYTES;
 	if (c->cfg.n_streams > 1 && stride < row)
 		return TFREC_AMD_E_INVAL;
-	HIPCHK(hipSetDevice(c->cfg.device));
-	const size_t need = row * (size_t)c->cfg.n_streams;
-	if (c->stage_bytes < need) {
-		HIPCHK(hipStreamSynchronize(c->last_stream));
-		(void)hipFree(c->d_stage);
-		c->d_stage = nullptr;
-		c->stage_bytes = 0;
-		if (hipMalloc((void **)&c->d_stage, need) != hipSuccess)
-			return TFREC_AMD_E_NOMEM;
-		c->stage_bytes = need;
+	if (c->inflight >= 2) {
+		snprintf(g_err, sizeof(g_err), "two submits are waiting to be drained: call tfrec_amd_drain_events first");
+		return TFREC_AMD_E_STATE;
 	}
-	// the staging buffer may still be read by the previous submit
-	HIPCHK(hipStreamSynchronize(c->last_stream));
-	HIPCHK(hipMemcpy2D(c->d_stage, row, h_iq, stride, row, (size_t)c->cfg.n_streams, hipMemcpyHostToDevice));
-	return tfrec_amd_submit_device(c, c->d_stage, row, n_blocks, nullptr);
+	HIPCHK(hipSetDevice(c->cfg.device));
+	const int set = (c->head + c->inflight) & 1;  // the set's previous user has been drained: its staging buffer is free
+	const size_t need = row * (size_t)c->cfg.n_streams;
+	if (c->stage_bytes[set] < need) {
+		(void)hipFree(c->d_stage[set]);
+		c->d_stage[set] = nullptr;
+		c->stage_bytes[set] = 0;
+		if (hipMalloc((void **)&c->d_stage[set], need) != hipSuccess)
+			return TFREC_AMD_E_NOMEM;
+		c->stage_bytes[set] = need;
+	}
+	// asynchronous on the front-end stream when h_iq is pinned (tfrec_amd_host_alloc); pageable memory is staged
+	// by the runtime before the call returns
+	HIPCHK(hipMemcpy2DAsync(c->d_stage[set], row, h_iq, stride, row, (size_t)c->cfg.n_streams, hipMemcpyHostToDevice, c->fs));
+	return submit_common(c, c->d_stage[set], row, n_blocks, nullptr, true);
+}
+
+void *tfrec_amd_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+		return nullptr;
+	return p;
+}
+
+void tfrec_amd_host_free(void *p)
+{
+	if (p)
+		(void)hipHostFree(p);
 }
 
 int tfrec_amd_sync(tfrec_amd_ctx *c)

@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 gpu_engine::gpu_engine(const std::vector<std::string> &dumpfiles, int _types, int _thresh, int _filter, int _dbg,
 		       int _device, int blocks_per_submit)
@@ -54,6 +57,11 @@ void gpu_engine::replay(const tfrec_amd_event &ev)
 	(void)before;
 }
 
+// engine::run (engine.cpp:63-93) for N files at once, as a three-stage pipeline over batches of bps blocks:
+//   reader thread : fread batch k+2 of every file into a pinned host buffer (three buffers in rotation)
+//   GPU           : H2D copy + hot path of batch k+1 (tfrec_amd_submit_host is asynchronous on pinned memory)
+//   this thread   : drain batch k's flush events and replay them into the decoders
+// The C ABI's submit/drain FIFO of depth two is what lets batch k+1 be queued before batch k is drained.
 int gpu_engine::run()
 {
 	const size_t n = files.size();
@@ -89,37 +97,91 @@ int gpu_engine::run()
 		return rc;
 	}
 	const size_t row = (size_t)bps * TFREC_AMD_BLOCK_BYTES;
-	std::vector<uint8_t> host(n * row);
-	std::vector<tfrec_amd_event> ev(cfg.max_events);
-	for (size_t b0 = 0; b0 < max_blocks && rc == 0; b0 += bps) {
-		const int nb = (int)std::min<size_t>(bps, max_blocks - b0);
-		for (size_t s = 0; s < n; s++) {
-			uint8_t *dst = &host[s * row];
-			const size_t want = (size_t)nb * TFREC_AMD_BLOCK_BYTES;
-			size_t got = fread(dst, 1, want, fd[s]);
-			got -= got % TFREC_AMD_BLOCK_BYTES;
-			memset(dst + got, 0x80, want - got);  // a shorter file is padded with silence (its events are cut below)
+	const size_t n_batches = (max_blocks + bps - 1) / bps;
+	constexpr int kBufs = 3;
+	uint8_t *host[kBufs];
+	bool pinned = true;
+	for (int b = 0; b < kBufs; b++) {
+		host[b] = (uint8_t *)tfrec_amd_host_alloc(n * row);
+		if (!host[b]) {  // no page-locked memory: the copies become synchronous, results are the same
+			pinned = false;
+			host[b] = (uint8_t *)malloc(n * row);
 		}
-		rc = tfrec_amd_submit_host(ctx, host.data(), row, nb);
-		if (rc)
+	}
+	// ---- reader thread: batch k goes to host[k % kBufs]; it may run at most kBufs batches ahead of the drain
+	std::mutex mu;
+	std::condition_variable cv;
+	size_t filled = 0, drained = 0;  // batches read / batches whose buffer is free again
+	std::thread reader([&]() {
+		for (size_t k = 0; k < n_batches; k++) {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return k < drained + kBufs; });
+			}
+			const int nb = (int)std::min<size_t>(bps, max_blocks - k * bps);
+			uint8_t *buf = host[k % kBufs];
+			for (size_t s = 0; s < n; s++) {
+				uint8_t *dst = buf + s * row;
+				const size_t want = (size_t)nb * TFREC_AMD_BLOCK_BYTES;
+				size_t got = fread(dst, 1, want, fd[s]);
+				got -= got % TFREC_AMD_BLOCK_BYTES;
+				memset(dst + got, 0x80, want - got);  // a shorter file is padded with silence (its events are cut below)
+			}
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				filled = k + 1;
+			}
+			cv.notify_all();
+		}
+	});
+	std::vector<tfrec_amd_event> ev(cfg.max_events);
+	auto submit = [&](size_t k) -> int {
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&]() { return filled > k; });
+		}
+		const int nb = (int)std::min<size_t>(bps, max_blocks - k * bps);
+		return tfrec_amd_submit_host(ctx, host[k % kBufs], row, nb);
+	};
+	if (n_batches > 0)
+		rc = submit(0);
+	for (size_t k = 0; k < n_batches && rc == 0; k++) {
+		if (k + 1 < n_batches && (rc = submit(k + 1)) != 0)
 			break;
 		int nev = 0;
 		rc = tfrec_amd_drain_events(ctx, ev.data(), (int)ev.size(), &nev);
 		if (rc)
 			break;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			drained = k + 1;  // batch k's host buffer may be refilled
+		}
+		cv.notify_all();
 		// per stream in time order, slots in registration order like the reference's dispatch loop (fm_demod.cpp:48-49)
 		std::sort(ev.begin(), ev.begin() + nev, [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
 			if (a.stream != b.stream) return a.stream < b.stream;
 			if (a.end_sample != b.end_sample) return a.end_sample < b.end_sample;
 			return a.slot < b.slot;
 		});
-		for (int k = 0; k < nev; k++)
-			if (ev[k].end_sample < stream_samples[ev[k].stream])
-				replay(ev[k]);
+		for (int q = 0; q < nev; q++)
+			if (ev[q].end_sample < stream_samples[ev[q].stream])
+				replay(ev[q]);
 	}
 	if (rc)
 		fprintf(stderr, "tfrec_amd: %s (%s)\n", tfrec_amd_strerror(rc), tfrec_amd_last_error());
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		drained = n_batches + kBufs;  // let the reader run out after an error
+	}
+	cv.notify_all();
+	reader.join();
 	tfrec_amd_destroy(ctx);
+	for (int b = 0; b < kBufs; b++) {
+		if (pinned)
+			tfrec_amd_host_free(host[b]);
+		else
+			free(host[b]);
+	}
 	for (size_t s = 0; s < n; s++)
 		fclose(fd[s]);
 	return rc;
