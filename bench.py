@@ -91,7 +91,11 @@ def main():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic streams to generate per GPU (0 = auto)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--parity-streams", type=int, default=4)
+    ap.add_argument("--input-10x", action="store_true",
+                    help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
+                         "(secondary measurement; the default line stays config 2)")
     a = ap.parse_args()
+    rate = 10 if a.input_10x else 1
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,12 +114,17 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n_streams, n_blocks = a.streams, a.blocks
-    row = n_blocks * api.BLOCK_BYTES
+    row = n_blocks * api.BLOCK_BYTES * rate
     # ---- synthetic input: distinct seeds per rank; generate `unique` streams and tile them over the batch
     ncpu = os.cpu_count() or 1
     unique = a.unique if a.unique > 0 else (n_streams if ncpu >= 32 else min(n_streams, max(16, 8 * ncpu)))
     t0 = time.perf_counter()
-    host = synth.gen_batch(1000 + rank, rank * n_streams, unique, n_blocks)
+    if rate == 1:
+        host = synth.gen_batch(1000 + rank, rank * n_streams, unique, n_blocks)
+    else:
+        unique = min(unique, 32)
+        host = np.stack([synth.gen_stream(1000 + rank, rank * n_streams + s, n_blocks, 0x1F, 256, rate_mult=rate)
+                         for s in range(unique)])
     t_gen = time.perf_counter() - t0
     d_iq = torch.empty((n_streams, row), dtype=torch.uint8, device=dev)
     d_u = torch.from_numpy(host).to(dev)
@@ -126,7 +135,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     r = api.Receiver(n_streams, a.types, a.thresh, 0, device=local_rank, max_blocks=n_blocks, timing=True,
-                     max_events=max(4096, n_streams * 256))
+                     max_events=max(4096, n_streams * 256), input_10x=a.input_10x)
 
     # ---- parity gate on this rank's first streams (fresh context state): GPU events == oracle events
     parity_ok = None
@@ -139,7 +148,10 @@ def main():
         parity_ok = True
         for s in range(min(a.parity_streams, unique)):
             o = O.Oracle(a.types, a.thresh, 0)
-            o.process(host[s])
+            if rate == 1:
+                o.process(host[s])
+            else:
+                o.process_s16(O.decim10(host[s]))
             want = sorted(e for e in o.events() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
                           and not (e[0] == 4 and e[2] > 60))
             got = sorted(api.event_tuples(first, s))
@@ -181,7 +193,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    samples_per_step_gpu = n_streams * n_blocks * SAMPLES_PER_BLOCK
+    samples_per_step_gpu = n_streams * n_blocks * SAMPLES_PER_BLOCK * rate  # complex INPUT samples
     total_samples = samples_per_step_gpu * a.steps * world
     value = total_samples / elapsed / 1e6
 
@@ -215,7 +227,9 @@ def main():
             "data": "synthetic (tfrec_amd.synth, SURVEY App. C recipe; %d distinct streams per GPU%s)" % (
                 unique, "" if unique == n_streams else " tiled over %d" % n_streams),
             "config": {
-                "workload": "configs[2]: %d batched 1.536 MS/s streams x %d blocks x protocols mask 0x%x, -t %d, per GPU"
+                "workload": ("configs[4]: %d batched 15.36 MS/s streams (10:1 front end) x %d blocks x protocols mask 0x%x, -t %d, per GPU"
+                             if a.input_10x else
+                             "configs[2]: %d batched 1.536 MS/s streams x %d blocks x protocols mask 0x%x, -t %d, per GPU")
                             % (n_streams, n_blocks, a.types, a.thresh),
                 "streams_per_gpu": n_streams, "blocks_per_stream": n_blocks, "types_mask": a.types,
                 "thresh": a.thresh, "parallelism": "streams sharded by index, no collective",
@@ -231,7 +245,7 @@ def main():
                 "speculation_stats": r.stats(),
             },
         }
-        if a.cpu_budget > 0 and world == 1:
+        if a.cpu_budget > 0 and world == 1 and rate == 1:
             out["cpu_baseline"] = cpu_baseline(host[: min(unique, 64)], a.types, a.thresh, a.cpu_budget)
         print(json.dumps(out), flush=True)
     r.close()

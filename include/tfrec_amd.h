@@ -33,6 +33,7 @@ extern "C" {
 #endif
 
 #define TFREC_AMD_BLOCK_BYTES 65536 /* RLS, engine.cpp:68 */
+#define TFREC_AMD_BLOCK_BYTES_10X 655360 /* one block of a 15.36 MS/s stream (TFREC_AMD_F_INPUT_10X) */
 #define TFREC_AMD_BLOCK_DEC 8192    /* decimated IQ pairs per block (4:1, dsp_stuff.cpp:243-264) */
 #define TFREC_AMD_NSLOTS 5
 
@@ -55,6 +56,10 @@ enum {
 				      only flushes whose byte_cnt reaches the decoder's minimum length
 				      (tfa1.cpp:49, tfa2.cpp:76/222, whb.cpp:484) */
 #define TFREC_AMD_F_TIMING 2u      /* record HIP events around every kernel (tfrec_amd_get_timings) */
+#define TFREC_AMD_F_INPUT_10X 8u   /* BASELINE config 5: the input is u8 IQ at 15.36 MS/s (TFREC_AMD_BLOCK_BYTES_10X bytes per
+				      block and stream); a 10:1 decimating FIR in the reference's integer style (60 int16
+				      taps, >>16 per tap, int16 store; defined in DESIGN.md, no reference counterpart)
+				      produces the 1.536 MS/s int16 stream that enters downconvert::process_iq */
 #define TFREC_AMD_F_SERIAL_CHAINS 4u /* run the demodulators as one serial lane per (stream, slot) -- the simple
 				      GPU formulation kept as a cross-check of the window-parallel pipeline */
 
@@ -141,6 +146,8 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *ctx, int *n);
  * reference's host expressions (tfa1.cpp:180, tfa2.cpp:434, whb.cpp:696) including (int)(10*log10(0)). */
 int tfrec_amd_rssi_db(int slot, int64_t rssi_raw);
 
+/* Parity/debug (TFREC_AMD_F_INPUT_10X): the 1.536 MS/s int16 IQ the 10:1 stage produced for the last submit. */
+int tfrec_amd_read_stage0(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_t n_pairs);
 /* Parity/debug: copy the decimated int16 IQ of the last submit for one stream (n_pairs*2 int16). */
 int tfrec_amd_read_decimated(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_t n_pairs);
 /* Samples whose FM-discriminator truncation was closer than 1e-9 to an integer boundary. */

@@ -8,6 +8,7 @@ fixtures the CPU tests replay on any machine:
 
   tests/golden/kat_bytes.json     byte-level known answers (README.md:123 + SURVEY App. D) through -X
   tests/golden/streams.json       generator parameters + reference events/data/text/hashes
+  tests/golden/config5.json       the same for BASELINE config 5 (15.36 MS/s input, 10:1 stage, int16 entry)
   tests/golden/iq_*.npz           small raw IQ captures with the reference's outputs (generator-independent)
   tests/golden/unit_probes.npz    fm_dev / fm_dev_nrzs / iir2::step probes of the reference functions
 
@@ -165,6 +166,42 @@ def mint_streams(tmp):
                        cases=cases), f, indent=0)
 
 
+CONFIG5_CASES = [
+    # 15.36 MS/s streams (generator rate_mult 10) -> oracle.decim10 -> the real reference's int16 entry (run16)
+    dict(seed=31, stream=0, n_blocks=12, proto_mask=0x1F, noise_q8=256, types=0x2F, thresh=500, wide=0),
+    dict(seed=31, stream=1, n_blocks=12, proto_mask=0x1F, noise_q8=512, types=0x2F, thresh=500, wide=1),
+]
+
+
+def mint_config5(tmp):
+    """BASELINE config 5.  The 10:1 stage has no reference counterpart (its output is pinned only as a hash of
+    the C restatement's own result); everything after it is the real reference fed with that int16 stream."""
+    cases = []
+    for c in CONFIG5_CASES:
+        iq = synth.gen_stream(c["seed"], c["stream"], c["n_blocks"], c["proto_mask"], c["noise_q8"], rate_mult=10)
+        x16 = O.decim10(iq)
+        p = os.path.join(tmp, "c5.s16")
+        x16.tofile(p)
+        ref = O.run_reference(p, c["types"], c["thresh"], c["wide"], tmp, bits=True, in16=True)
+        o = O.Oracle(c["types"], c["thresh"], c["wide"], log_bits=True, keep_dec=True)
+        o.process_s16(x16)
+        tag = "config5 case %r" % c
+        check(np.array_equal(o.dec(), ref["dec"]), tag + ": decimated samples")
+        check(o.events() == ref["events"], tag + ": flush events")
+        check(o.data() == ref["data"], tag + ": store_data records")
+        check(o.text() == ref["text"], tag + ": telegram text")
+        check(o.bits_text() == ref["bits"], tag + ": store_bit log")
+        d = dict(c)
+        d.update(iq_sha256=sha(iq), stage0_sha256=sha(x16), dec_sha256=sha(ref["dec"]), events=events_to_json(ref["events"]),
+                 data=data_to_json(ref["data"]), text=ref["text"])
+        cases.append(d)
+        print("config5 case seed=%d stream=%d: %d flushes, %d text lines" % (c["seed"], c["stream"], len(ref["events"]),
+                                                                             len(ref["text"].splitlines())))
+    with open(os.path.join(GOLD, "config5.json"), "w") as f:
+        json.dump(dict(source="tfrec_amd.synth rate_mult=10 -> oracle.decim10 (defined here) -> oracle/_ref/ref_driver "
+                              "run16 (real reference hot path on int16 input)", cases=cases), f, indent=0)
+
+
 def mint_iq_fixtures(tmp):
     """Short raw captures around one burst per protocol, stored with the reference's outputs."""
     for proto in range(5):
@@ -252,6 +289,7 @@ def main():
             mint_kats(tmp)
             mint_unit_probes()
             mint_streams(tmp)
+            mint_config5(tmp)
             mint_iq_fixtures(tmp)
         if a.campaign:
             campaign(a.campaign, tmp)

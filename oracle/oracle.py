@@ -70,6 +70,9 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
         L.orc_process.restype = C.c_long
         L.orc_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_process_s16.restype = C.c_long
+        L.orc_process_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_decim10.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_hex.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_num_events.restype = C.c_size_t
         L.orc_num_events.argtypes = [C.c_void_p]
@@ -143,6 +146,11 @@ class Oracle:
         iq = np.ascontiguousarray(iq, dtype=np.uint8)
         return int(self.L.orc_process(self.h, iq.ctypes.data, iq.size))
 
+    def process_s16(self, x: np.ndarray) -> int:
+        """Blocks of 65536 int16 values (already (I,Q) int16 at 1.536 MS/s: BASELINE config 5)."""
+        a = np.ascontiguousarray(x, dtype=np.int16)
+        return int(self.L.orc_process_s16(self.h, a.ctypes.data, a.size))
+
     def hex(self, data: bytes):
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
         self.L.orc_hex(self.h, buf, len(data))
@@ -203,11 +211,23 @@ def parse_ref_events(path: str):
     return ev, data, "".join(bits)
 
 
-def run_reference(iq_path: str, types_mask: int, thresh: int, wide: int, workdir: str, bits: bool = False):
-    """Run the real reference on an IQ file; returns dict(text, events, data, bits, dec)."""
+def decim10(iq: np.ndarray) -> np.ndarray:
+    """BASELINE config 5 front end (defined by the oracle, no reference counterpart): u8 IQ at 15.36 MS/s ->
+    interleaved int16 IQ at 1.536 MS/s, from zero history."""
+    a = np.ascontiguousarray(iq, dtype=np.uint8)
+    n_in = a.size // 2
+    assert n_in % 10 == 0
+    out = np.empty(2 * (n_in // 10), dtype=np.int16)
+    lib().orc_decim10(a.ctypes.data, n_in, out.ctypes.data)
+    return out
+
+
+def run_reference(iq_path: str, types_mask: int, thresh: int, wide: int, workdir: str, bits: bool = False,
+                  in16: bool = False):
+    """Run the real reference on an IQ file (u8, or raw int16 with in16); returns dict(text, events, data, bits, dec)."""
     evp = os.path.join(workdir, "ref.ev")
     decp = os.path.join(workdir, "ref.dec")
-    out = subprocess.run([REF_DRIVER, "run", "%x" % types_mask, str(thresh), str(wide), iq_path, evp, decp,
+    out = subprocess.run([REF_DRIVER, "run16" if in16 else "run", "%x" % types_mask, str(thresh), str(wide), iq_path, evp, decp,
                           "1" if bits else "0"], capture_output=True, text=True, check=True)
     text = out.stdout.split("---\n", 1)[1]
     ev, data, bt = parse_ref_events(evp)

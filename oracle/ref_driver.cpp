@@ -182,12 +182,30 @@ static void run_stream(const unsigned char *iq, size_t len, fsk_demod &fsk, int 
 	}
 }
 
+// The same loop for input that is already int16 (the 1.536 MS/s stream a high-rate front end hands to the
+// reference's downconvert::process_iq -- BASELINE config 5): engine.cpp:85-86 without the u8 conversion of :77-78.
+static void run_stream16(const int16_t *x, size_t n_values, fsk_demod &fsk, int filter, FILE *dec_fd)
+{
+	downconvert dc(2);
+	static int16_t data[BLOCK_BYTES];
+	cur_block = 0;
+	for (size_t pos = 0; pos + BLOCK_BYTES <= n_values; pos += BLOCK_BYTES) {
+		memcpy(data, x + pos, sizeof(data));
+		int ld = dc.process_iq(data, BLOCK_BYTES, filter);
+		if (dec_fd)
+			fwrite(data, sizeof(int16_t), ld, dec_fd);
+		fsk.process(data, ld);
+		cur_block++;
+	}
+}
+
 int main(int argc, char **argv)
 {
 	if (argc < 2)
 		return 1;
 	setvbuf(stdout, NULL, _IOFBF, 1 << 16);
-	if (!strcmp(argv[1], "run") && argc >= 6) {
+	if ((!strcmp(argv[1], "run") || !strcmp(argv[1], "run16")) && argc >= 6) {
+		const bool in16 = !strcmp(argv[1], "run16");  // input file: raw int16 interleaved IQ instead of u8
 		int types = strtol(argv[2], NULL, 16);
 		int thresh = atoi(argv[3]);
 		int wide = atoi(argv[4]);
@@ -204,7 +222,10 @@ int main(int argc, char **argv)
 		register_demods(demods, types, 0);
 		fsk_demod fsk(&demods, thresh, 0);
 		puts("---");  // separates constructor chatter from telegram lines
-		run_stream(iq, len, fsk, wide, dec_fd);
+		if (in16)
+			run_stream16((const int16_t *)iq, len / 2, fsk, wide, dec_fd);
+		else
+			run_stream(iq, len, fsk, wide, dec_fd);
 		if (ev_fd) fclose(ev_fd);
 		if (dec_fd) fclose(dec_fd);
 		fflush(stdout);

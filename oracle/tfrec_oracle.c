@@ -1093,6 +1093,63 @@ long orc_process(orc_t *o, const uint8_t *iq, size_t nbytes)
 	return blocks;
 }
 
+/* Blocks that are already int16 (BASELINE config 5: what a high-rate front end hands to process_iq): engine.cpp:85-86
+ * without the u8 conversion of :77-78.  n_values = int16 count, whole blocks of 65536 values are consumed. */
+long orc_process_s16(orc_t *o, const int16_t *x, size_t n_values)
+{
+	static const int NB = ORC_BLOCK_BYTES;
+	int16_t *y = (int16_t *)malloc(2 * ORC_BLOCK_DEC * sizeof(int16_t));
+	const int16_t *t2 = o->wide ? taps_s2_wide : taps_s2_narrow;
+	long blocks = 0;
+	for (size_t pos = 0; pos + NB <= n_values; pos += NB) {
+		decimate_channel(&o->hi, x + pos, NB / 2, t2, y);
+		decimate_channel(&o->hq, x + pos + 1, NB / 2, t2, y + 1);
+		if (o->keep_dec && !o->quiet) {
+			if (o->ndec + 2 * ORC_BLOCK_DEC > o->capdec) {
+				o->capdec = (o->capdec + 2 * ORC_BLOCK_DEC) * 2;
+				o->dec = (int16_t *)realloc(o->dec, o->capdec * sizeof(int16_t));
+			}
+			memcpy(o->dec + o->ndec, y, 2 * ORC_BLOCK_DEC * sizeof(int16_t));
+			o->ndec += 2 * ORC_BLOCK_DEC;
+		}
+		fsk_process(o, y, 2 * ORC_BLOCK_DEC);
+		o->block++;
+		blocks++;
+	}
+	free(y);
+	return blocks;
+}
+
+/* ---- BASELINE config 5: 15.36 MS/s u8 IQ -> 1.536 MS/s int16 IQ.  The reference has no such stage:
+ * this DEFINES it, in the reference's FIR style (int16 taps, arithmetic >>16 per tap, int16 store; compare
+ * dsp_stuff.cpp:204-230): 60-tap Hamming-windowed sinc, cut-off 768 kHz, unity DC gain, 10:1,
+ *   y[m] = int16( sum_{n<60} ( x[10 m - 50 + n] * h[n] ) >> 16 ),  x = (u8 - 128) << 6,  x[<0] = 0.
+ * Parity of this stage is "unpinned by the reference"; everything after it is pinned through run16. */
+const int16_t orc_taps10[60] = {
+	9,    27,   48,   72,   98,   121,  135,  132,  104,  44,   -53,  -185, -343, -511, -668,
+	-783, -826, -765, -572, -230, 269,  916,  1690, 2552, 3452, 4333, 5133, 5793, 6265, 6512,
+	6510, 6265, 5793, 5133, 4333, 3452, 2552, 1690, 916,  269,  -230, -572, -765, -826, -783,
+	-668, -511, -343, -185, -53,  44,   104,  132,  135,  121,  98,   72,   48,   27,   9,
+};
+
+/* stateless over a whole stream from zero history: n_in complex input samples (n_in % 10 == 0), out n_in/10 pairs */
+void orc_decim10(const uint8_t *iq, size_t n_in, int16_t *out)
+{
+	for (size_t m = 0; m < n_in / 10; m++) {
+		int32_t si = 0, sq = 0;
+		for (int n = 0; n < 60; n++) {
+			const long k = (long)(10 * m) - 50 + n;
+			if (k < 0)
+				continue;
+			const int32_t xi = ((int32_t)iq[2 * k] - 128) << 6, xq = ((int32_t)iq[2 * k + 1] - 128) << 6;
+			si += (xi * orc_taps10[n]) >> 16;
+			sq += (xq * orc_taps10[n]) >> 16;
+		}
+		out[2 * m] = (int16_t)si;
+		out[2 * m + 1] = (int16_t)sq;
+	}
+}
+
 /* main.cpp:45-49 with decoder::store_bytes (decoder.cpp:35-40) */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len)
 {

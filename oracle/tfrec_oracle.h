@@ -49,6 +49,12 @@ void orc_set_quiet(orc_t *o, int on); /* timing runs: no text, no event/data/bit
  * reference does.  Returns the number of blocks consumed. */
 long orc_process(orc_t *o, const uint8_t *iq, size_t nbytes);
 
+/* The same for blocks of 65536 int16 values (input that is already (I,Q) int16 at 1.536 MS/s). */
+long orc_process_s16(orc_t *o, const int16_t *x, size_t n_values);
+/* BASELINE config 5 front end (defined here, no reference counterpart): 15.36 MS/s u8 IQ -> 1.536 MS/s int16 IQ */
+extern const int16_t orc_taps10[60];
+void orc_decim10(const uint8_t *iq, size_t n_in_complex, int16_t *out);
+
 /* -X replay (main.cpp:24-53): store_bytes + flush(0) on every registered decoder. */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len);
 

@@ -19,7 +19,7 @@ def _no_gpu():
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "tfrec_amd.h")).read()
-    declared = sorted(set(re.findall(r"\b(tfrec_amd_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(tfrec_amd_[a-z0-9_]+)\s*\(", hdr)))
     assert set(declared) == set(api.EXPORTS)
     L = api.load_library()
     for name in declared:

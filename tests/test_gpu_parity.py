@@ -220,3 +220,28 @@ def test_two_submits_in_flight_fifo():
     for a, b in zip(ref, got):
         assert len(a) == len(b) and len(a) > 0
         assert a.tobytes() == b.tobytes()
+
+
+def test_config5_10x_front_end():
+    """BASELINE config 5: 15.36 MS/s u8 input -> 10:1 integer FIR (defined by this project, oracle.decim10) ->
+    the standard path on int16 input.  The 10:1 stage is checked bit for bit against its C restatement, everything
+    after it against the oracle's int16 entry (which the real reference pins through ref_driver run16)."""
+    n_streams, n_blocks = 3, 12
+    iq = np.stack([synth.gen_stream(31, s, n_blocks, 0x1F, 256, rate_mult=10) for s in range(n_streams)])
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=8, all_flushes=True, input_10x=True) as r:
+        evs = []
+        for a, b in ((0, 5), (5, 12)):  # history of both FIR stages carries across submits
+            r.submit(np.ascontiguousarray(iq[:, a * 655360:b * 655360]))
+            evs.append(r.drain())
+            for s in range(n_streams):
+                want = O.decim10(iq[s, : b * 655360])[2 * a * 32768:]
+                got = r.stage0(s, (b - a) * 32768)
+                assert np.array_equal(got, want), "10:1 stage, stream %d" % s
+        ev = np.concatenate(evs)
+        ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
+        total = 0
+        for s in range(n_streams):
+            o = O.Oracle(0x2F, 500, 0)
+            o.process_s16(O.decim10(iq[s]))
+            total += check_stream(ev, s, o)
+        assert total >= 10

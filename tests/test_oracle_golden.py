@@ -72,6 +72,24 @@ def test_synthetic_streams_against_reference_outputs(golden_dir):
         assert o.text() == c["text"]
 
 
+def test_config5_int16_entry_against_reference_outputs(golden_dir):
+    """BASELINE config 5: 15.36 MS/s input -> 10:1 stage (defined by this project) -> the reference's int16 entry."""
+    cases = json.load(open(os.path.join(golden_dir, "config5.json")))["cases"]
+    assert len(cases) >= 2
+    for c in cases:
+        iq = synth.gen_stream(c["seed"], c["stream"], c["n_blocks"], c["proto_mask"], c["noise_q8"], rate_mult=10)
+        assert _sha(iq) == c["iq_sha256"], "generator drifted: seed %d stream %d" % (c["seed"], c["stream"])
+        x16 = O.decim10(iq)
+        assert _sha(x16) == c["stage0_sha256"]
+        o = O.Oracle(c["types"], c["thresh"], c["wide"], keep_dec=True)
+        assert o.process_s16(x16) == c["n_blocks"]
+        assert _sha(o.dec()) == c["dec_sha256"]
+        assert o.events() == _events(c["events"])
+        assert o.data() == _data(c["data"])
+        assert o.text() == c["text"]
+        assert len(o.events()) >= 10
+
+
 @pytest.mark.parametrize("name", ["tfa_1", "tfa_2", "tfa_3", "tx22", "whb"])
 def test_raw_iq_fixtures(golden_dir, name):
     z = np.load(os.path.join(golden_dir, "iq_%s.npz" % name))

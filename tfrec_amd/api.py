@@ -21,6 +21,7 @@ SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
 F_ALL_FLUSHES = 1
 F_TIMING = 2
 F_SERIAL_CHAINS = 4
+F_INPUT_10X = 8
 
 E_OK, E_INVAL, E_NOMEM, E_HIP, E_OVERFLOW, E_STATE = 0, -1, -2, -3, -4, -5
 
@@ -77,7 +78,7 @@ EXPORTS = (
     "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
     "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_host_alloc",
-    "tfrec_amd_host_free",
+    "tfrec_amd_host_free", "tfrec_amd_read_stage0",
 )
 
 _lib = None
@@ -122,6 +123,7 @@ def load_library(build: bool = True):
     L.tfrec_amd_rssi_db.argtypes = [C.c_int, C.c_int64]
     L.tfrec_amd_rssi_db.restype = C.c_int
     L.tfrec_amd_read_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.tfrec_amd_read_stage0.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.tfrec_amd_atan_uncertain.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tfrec_amd_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.tfrec_amd_read_thresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -150,12 +152,13 @@ class Receiver:
 
     def __init__(self, n_streams: int, types_mask: int = 0x2F, thresh: int = 500, filter_type: int = 0,
                  device: int = 0, max_blocks: int = 48, max_events: int | None = None, all_flushes: bool = False,
-                 timing: bool = False, serial_chains: bool = False):
+                 timing: bool = False, serial_chains: bool = False, input_10x: bool = False):
         self.L = load_library()
         if max_events is None:
             max_events = max(4096, n_streams * max_blocks * 4 * (8 if all_flushes else 2))
         flags = ((F_ALL_FLUSHES if all_flushes else 0) | (F_TIMING if timing else 0)
-                 | (F_SERIAL_CHAINS if serial_chains else 0))
+                 | (F_SERIAL_CHAINS if serial_chains else 0) | (F_INPUT_10X if input_10x else 0))
+        self.block_bytes = BLOCK_BYTES * (10 if input_10x else 1)
         self.cfg = Config(n_streams, types_mask, thresh, filter_type, device, max_blocks, max_events, flags)
         self.h = C.c_void_p()
         _check(self.L, self.L.tfrec_amd_create(C.byref(self.cfg), C.byref(self.h)))
@@ -184,14 +187,14 @@ class Receiver:
         """iq: torch uint8 CUDA tensor [n_streams, n_bytes] (resident in HBM) or a numpy/host array."""
         if isinstance(iq, np.ndarray):
             a = np.ascontiguousarray(iq, dtype=np.uint8).reshape(self.n_streams, -1)
-            nb = a.shape[1] // BLOCK_BYTES if n_blocks is None else n_blocks
+            nb = a.shape[1] // self.block_bytes if n_blocks is None else n_blocks
             _check(self.L, self.L.tfrec_amd_submit_host(self.h, a.ctypes.data, a.strides[0], nb))
             return nb
         import torch
 
         assert iq.is_cuda and iq.dtype == torch.uint8 and iq.dim() == 2 and iq.shape[0] == self.n_streams
         assert iq.stride(1) == 1
-        nb = iq.shape[1] // BLOCK_BYTES if n_blocks is None else n_blocks
+        nb = iq.shape[1] // self.block_bytes if n_blocks is None else n_blocks
         st = torch.cuda.current_stream(iq.device) if stream is None else stream
         self._keep = (getattr(self, "_keep", ()) + (iq,))[-2:]  # inputs stay alive while their submit may be in flight
         _check(self.L, self.L.tfrec_amd_submit_device(self.h, C.c_void_p(iq.data_ptr()), iq.stride(0), nb,
@@ -207,6 +210,12 @@ class Receiver:
         rc = self.L.tfrec_amd_drain_events(self.h, out.ctypes.data, self.max_events, C.byref(n))
         _check(self.L, rc, ok=(E_OK, E_OVERFLOW) if allow_overflow else (E_OK,))
         return out[: n.value]
+
+    def stage0(self, stream: int, n_pairs: int) -> np.ndarray:
+        """input_10x: the 1.536 MS/s int16 IQ the 10:1 stage produced for the last submit."""
+        out = np.empty(2 * n_pairs, dtype=np.int16)
+        _check(self.L, self.L.tfrec_amd_read_stage0(self.h, stream, out.ctypes.data, n_pairs))
+        return out
 
     def decimated(self, stream: int, n_pairs: int) -> np.ndarray:
         out = np.empty(2 * n_pairs, dtype=np.int16)

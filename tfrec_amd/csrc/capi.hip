@@ -10,10 +10,12 @@
 #include "tfrec_dev.h"
 
 namespace tfrec {
+hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
+			  const uint8_t *tail_in, uint8_t *tail_out, uint32_t *out, size_t out_stride);
 hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
 			   unsigned long long *mask, size_t mask_stride, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			   int thresh, const FrontTaps &taps);
+			   int thresh, const FrontTaps &taps, bool in16);
 hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
@@ -67,6 +69,11 @@ struct tfrec_amd_ctx {
 	int wmax = 0;
 	uint8_t *d_tail[2] = { nullptr, nullptr };
 	int tail_sel = 0;
+	// TFREC_AMD_F_INPUT_10X: output of the 10:1 stage (1.536 MS/s int16 pairs, one buffer per set) and its raw history
+	uint32_t *d_in16[2] = { nullptr, nullptr };
+	size_t in16_stride = 0;  // uint32 units
+	uint8_t *d_tail10[2] = { nullptr, nullptr };
+	bool in10x = false;
 	// Two event buffer sets: a submit may be queued while the host still drains the previous one (FIFO, depth 2)
 	tfrec_amd_event *d_events[2] = { nullptr, nullptr };
 	EventBuf *d_eb[2] = { nullptr, nullptr };
@@ -191,6 +198,10 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_fsk);
 	(void)hipFree(c->d_tail[0]);
 	(void)hipFree(c->d_tail[1]);
+	for (int k = 0; k < 2; k++) {
+		(void)hipFree(c->d_in16[k]);
+		(void)hipFree(c->d_tail10[k]);
+	}
 	for (int k = 0; k < 2; k++) {
 		(void)hipFree(c->d_events[k]);
 		(void)hipFree(c->d_eb[k]);
@@ -391,8 +402,17 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 				rc = TFREC_AMD_E_HIP;
 		}
 	}
-	ALLOC(c->d_tail[0], n * kTailBytes);
-	ALLOC(c->d_tail[1], n * kTailBytes);
+	c->in10x = (cfg->flags & TFREC_AMD_F_INPUT_10X) != 0;
+	const size_t tail_bytes = c->in10x ? 2 * (size_t)kTailBytes : (size_t)kTailBytes;  // int16 history is twice as wide
+	ALLOC(c->d_tail[0], n * tail_bytes);
+	ALLOC(c->d_tail[1], n * tail_bytes);
+	if (c->in10x) {
+		c->in16_stride = 4 * m_max;  // complex samples at 1.536 MS/s per stream and submit
+		for (int k = 0; k < 2; k++) {
+			ALLOC(c->d_in16[k], n * c->in16_stride * sizeof(uint32_t));
+			ALLOC(c->d_tail10[k], n * 112);
+		}
+	}
 	for (int k = 0; k < 2; k++) {
 		ALLOC(c->d_events[k], (size_t)cfg->max_events * sizeof(tfrec_amd_event));
 		ALLOC(c->d_eb[k], sizeof(EventBuf));
@@ -410,8 +430,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb = { 0u, (uint32_t)cfg->max_events, 0ull };
-		if (hipMemset(c->d_tail[0], 0x80, n * kTailBytes) != hipSuccess ||
-		    hipMemset(c->d_tail[1], 0x80, n * kTailBytes) != hipSuccess ||
+		// (int16 history of the 10x path: zero; raw u8 history of its 10:1 stage: 128)
+		if (hipMemset(c->d_tail[0], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
+		    hipMemset(c->d_tail[1], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
+		    (c->in10x && (hipMemset(c->d_tail10[0], 0x80, n * 112) != hipSuccess ||
+				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
 		    hipMemcpy(c->d_eb[0], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(c->d_eb[1], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
@@ -461,8 +484,9 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 {
 	if (!c || !d_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
 		return TFREC_AMD_E_INVAL;
+	const size_t block_bytes = c->in10x ? TFREC_AMD_BLOCK_BYTES_10X : TFREC_AMD_BLOCK_BYTES;
 	if ((stride % 16) != 0 || ((uintptr_t)d_iq % 16) != 0 ||
-	    (c->cfg.n_streams > 1 && stride < (size_t)n_blocks * TFREC_AMD_BLOCK_BYTES)) {
+	    (c->cfg.n_streams > 1 && stride < (size_t)n_blocks * block_bytes)) {
 		snprintf(g_err, sizeof(g_err), "IQ base and stream stride must be 16-byte aligned and >= one stream");
 		return TFREC_AMD_E_INVAL;
 	}
@@ -484,9 +508,18 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf), hipMemcpyDeviceToDevice, fs));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][0], fs));
-	HIPCHK(launch_frontend(fs, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
+	const uint8_t *fin = (const uint8_t *)d_iq;
+	size_t fstride = stride;
+	if (c->in10x) {  // 15.36 MS/s u8 -> 1.536 MS/s int16 pairs, then the standard cascade on int16 input
+		HIPCHK(launch_decim10(fs, (const uint8_t *)d_iq, stride, c->cfg.n_streams, n_blocks, c->d_tail10[c->tail_sel],
+				      c->d_tail10[c->tail_sel ^ 1], c->d_in16[set], c->in16_stride));
+		fin = (const uint8_t *)c->d_in16[set];
+		fstride = c->in16_stride * sizeof(uint32_t);
+	}
+	HIPCHK(launch_frontend(fs, fin, fstride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
 			       c->d_tail[c->tail_sel ^ 1], c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride,
-			       c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps));
+			       c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps,
+			       c->in10x));
 	if (c->d_fsk)  // auto threshold: per-block thresholds rewrite the trigger mask (fm_demod.cpp:58-73)
 		HIPCHK(launch_threshold(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams,
 					n_blocks, c->d_fsk, c->wmax));
@@ -525,7 +558,7 @@ int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, 
 {
 	if (!c || !h_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
 		return TFREC_AMD_E_INVAL;
-	const size_t row = (size_t)n_blocks * TFREC_AMD_BLOCK_BYTES;
+	const size_t row = (size_t)n_blocks * (c->in10x ? TFREC_AMD_BLOCK_BYTES_10X : TFREC_AMD_BLOCK_BYTES);
 	if (c->cfg.n_streams > 1 && stride < row)
 		return TFREC_AMD_E_INVAL;
 	if (c->inflight >= 2) {
@@ -639,6 +672,19 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 		memcpy(out, tmp, (size_t)ncopy * sizeof(tfrec_amd_event));
 	*n_out = (int)ncopy;
 	return overflow ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
+}
+
+int tfrec_amd_read_stage0(tfrec_amd_ctx *c, int stream, int16_t *out, size_t n_pairs)
+{
+	if (!c || !out || !c->in10x || stream < 0 || stream >= c->cfg.n_streams ||
+	    n_pairs > (size_t)c->last_blocks * 4 * kBlockDec)
+		return TFREC_AMD_E_INVAL;
+	int rc = tfrec_amd_sync(c);
+	if (rc)
+		return rc;
+	HIPCHK(hipMemcpy(out, c->d_in16[c->last_set] + (size_t)stream * c->in16_stride, n_pairs * sizeof(uint32_t),
+			 hipMemcpyDeviceToHost));
+	return TFREC_AMD_OK;
 }
 
 int tfrec_amd_read_decimated(tfrec_amd_ctx *c, int stream, int16_t *out, size_t n_pairs)

@@ -46,13 +46,20 @@ __device__ __forceinline__ unsigned long long spread4(unsigned long long x)
 	return x;
 }
 
+// IN16 = false: raw input is u8 IQ, x = (u8 - 128) << 6 (engine.cpp:77-78).  IN16 = true: the input already is
+// int16 (I,Q) pairs at 1.536 MS/s (what decim10_kernel produces for BASELINE config 5): 4 bytes per complex
+// sample instead of 2, per-tap (x*h)>>16 without the <<6 shortcut.
+template <bool IN16>
 __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const uint8_t *__restrict__ iq, size_t stride, int m_total, const uint8_t *__restrict__ tail_in,
 	uint8_t *__restrict__ tail_out, uint32_t *__restrict__ dec, size_t dec_stride,
 	unsigned long long *__restrict__ mask, size_t mask_stride, int16_t *__restrict__ fmdev, size_t fmdev_stride,
 	EventBuf *__restrict__ eb, int thresh, FrontTaps taps)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t raw[kRawChunks * 16];
+	constexpr int kB = IN16 ? 2 : 1;             // bytes per rail sample
+	constexpr int kTail = kTailBytes * kB;      // history bytes (56 complex samples)
+	constexpr int kChunks = (kTail + 8 * kB * kTileDec + 16 * kB + 15) / 16;
+	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
 	__shared__ __attribute__((aligned(16))) int32_t y1i[kY1Count];
 	__shared__ __attribute__((aligned(16))) int32_t y1q[kY1Count];
 	__shared__ uint32_t lastw[kFrontThreads];
@@ -61,41 +68,50 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const int tile = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
-	const long nbytes = 8L * m_total;
+	const long nbytes = 8L * kB * m_total;
 	const uint8_t *src = iq + (size_t)s * stride;
 
-	// ---- stage raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) into LDS, 16 B per lane, coalesced
-	const long base = 8L * m0 - kTailBytes;
-	for (int c = tid; c < kRawChunks; c += kFrontThreads) {
+	// ---- stage raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) into LDS, 16 B per lane, coalesced
+	const long base = 8L * kB * m0 - kTail;
+	const uint32_t silence = IN16 ? 0u : 0x80808080u;
+	for (int c = tid; c < kChunks; c += kFrontThreads) {
 		const long bo = base + 16L * c;
 		uint4 v;
 		if (bo >= 0 && bo + 16 <= nbytes)
 			v = *reinterpret_cast<const uint4 *>(src + bo);
 		else if (bo < 0)
-			v = *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTailBytes + (kTailBytes + bo));
+			v = *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTail + (kTail + bo));
 		else
-			v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+			v = make_uint4(silence, silence, silence, silence);
 		*reinterpret_cast<uint4 *>(raw + 16 * c) = v;
 	}
-	// history for the next submit: last 112 raw bytes of this one
-	if (tile == (int)gridDim.x - 1 && tid < kTailBytes / 16)
-		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTailBytes + 16 * tid) =
-			*reinterpret_cast<const uint4 *>(src + nbytes - kTailBytes + 16 * tid);
+	// history for the next submit: the last 56 raw complex samples of this one
+	if (tile == (int)gridDim.x - 1 && tid < kTail / 16)
+		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail + 16 * tid) =
+			*reinterpret_cast<const uint4 *>(src + nbytes - kTail + 16 * tid);
 	__syncthreads();
 
 	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes 4 consecutive outputs of both rails.
 	// Outputs k..k+3 need x[2k-6 .. 2k+7]: 28 raw bytes at LDS offset 12 + 16*grp (k = 2*m0 - 22 + 4*grp).
 	constexpr int kGroups = (2 * kTileDec + 24 + 3) / 4;
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
-		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + 12 + 16 * grp);
+		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + kB * (12 + 16 * grp));
 		int di[14], dq[14];
+		if (IN16) {
 #pragma unroll
-		for (int i = 0; i < 7; i++) {
-			const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
-			di[2 * i] = (int)(int8_t)(w & 0xff);
-			dq[2 * i] = (int)(int8_t)((w >> 8) & 0xff);
-			di[2 * i + 1] = (int)(int8_t)((w >> 16) & 0xff);
-			dq[2 * i + 1] = (int)w >> 24;
+			for (int i = 0; i < 14; i++) {
+				di[i] = (int)(int16_t)(rp[i] & 0xffff);
+				dq[i] = (int)rp[i] >> 16;
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < 7; i++) {
+				const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
+				di[2 * i] = (int)(int8_t)(w & 0xff);
+				dq[2 * i] = (int)(int8_t)((w >> 8) & 0xff);
+				di[2 * i + 1] = (int)(int8_t)((w >> 16) & 0xff);
+				dq[2 * i + 1] = (int)w >> 24;
+			}
 		}
 		int oi[4], oq[4];
 #pragma unroll
@@ -103,8 +119,8 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			int si = 0, sq = 0;
 #pragma unroll
 			for (int n = 0; n < 8; n++) {
-				si += (di[2 * o + n] * kS1[n]) >> 10;
-				sq += (dq[2 * o + n] * kS1[n]) >> 10;
+				si += (di[2 * o + n] * kS1[n]) >> (IN16 ? 16 : 10);
+				sq += (dq[2 * o + n] * kS1[n]) >> (IN16 ? 16 : 10);
 			}
 			oi[o] = (int)(int16_t)si << 8;
 			oq[o] = (int)(int16_t)sq << 8;
@@ -192,15 +208,97 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		make_uint2(((uint32_t)dv[0] & 0xffffu) | ((uint32_t)dv[1] << 16), ((uint32_t)dv[2] & 0xffffu) | ((uint32_t)dv[3] << 16));
 }
 
+// ---- BASELINE config 5: 15.36 MS/s u8 IQ -> 1.536 MS/s int16 (I,Q).  The reference has no such stage; it is defined
+// (oracle/tfrec_oracle.c: orc_decim10) in the reference's FIR style: 60 int16 taps (Hamming-windowed sinc, cut-off
+// 768 kHz, unity DC gain), arithmetic >>16 per tap, int16 store, 10:1:
+//   y[m] = int16( sum_{n<60} ( x[10 m - 50 + n] * h[n] ) >> 16 ),  x = (u8 - 128) << 6   (so (x*h)>>16 = ((u8-128)*h)>>10)
+// One 256-thread workgroup per tile of 1024 outputs: the tile's 20 KiB of raw bytes + 112 B of history are staged
+// into LDS with coalesced 16-byte loads (10x the bytes per output of the standard front end: this is the stage
+// that streams HBM); a lane makes 4 consecutive outputs of both rails from 180 LDS bytes.
+constexpr int kT10 = 1024;
+constexpr int kTail10 = 112;  // 56 complex samples of history (50 needed), 16-byte multiple
+__device__ __constant__ const int kTaps10[60] = {
+	9,    27,   48,   72,   98,   121,  135,  132,  104,  44,   -53,  -185, -343, -511, -668,
+	-783, -826, -765, -572, -230, 269,  916,  1690, 2552, 3452, 4333, 5133, 5793, 6265, 6512,
+	6510, 6265, 5793, 5133, 4333, 3452, 2552, 1690, 916,  269,  -230, -572, -765, -826, -783,
+	-668, -511, -343, -185, -53,  44,   104,  132,  135,  121,  98,   72,   48,   27,   9,
+};
+
+__global__ __launch_bounds__(256) void decim10_kernel(const uint8_t *__restrict__ iq, size_t stride, long n_out,
+						      const uint8_t *__restrict__ tail_in, uint8_t *__restrict__ tail_out,
+						      uint32_t *__restrict__ out, size_t out_stride)
+{
+	constexpr int kChunks = (kTail10 + 20 * kT10) / 16;
+	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
+	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+	const long m0 = (long)tile * kT10;
+	const long nbytes = 20L * n_out;
+	const uint8_t *src = iq + (size_t)s * stride;
+	// raw bytes [20*m0 - 112, 20*m0 + 20*T): LDS complex sample c <-> input sample 10*m0 - 56 + c
+	const long base = 20L * m0 - kTail10;
+	for (int c = tid; c < kChunks; c += 256) {
+		const long bo = base + 16L * c;
+		uint4 v;
+		if (bo >= 0)
+			v = *reinterpret_cast<const uint4 *>(src + bo);
+		else
+			v = *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTail10 + (kTail10 + bo));
+		*reinterpret_cast<uint4 *>(raw + 16 * c) = v;
+	}
+	if (tile == (int)gridDim.x - 1 && tid < kTail10 / 16)
+		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail10 + 16 * tid) =
+			*reinterpret_cast<const uint4 *>(src + nbytes - kTail10 + 16 * tid);
+	__syncthreads();
+	// outputs m0 + 4*tid + o: x[10 m - 50 + n] is LDS sample 10*(4*tid + o) + 6 + n -> 90 samples from 40*tid + 6
+	const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + 2 * (40 * tid + 6));
+	int acc_i[4] = { 0, 0, 0, 0 }, acc_q[4] = { 0, 0, 0, 0 };
+#pragma unroll
+	for (int w = 0; w < 45; w++) {  // one dword = two complex samples
+		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
+		const int xi[2] = { (int)(int8_t)(v & 0xff), (int)(int8_t)((v >> 16) & 0xff) };
+		const int xq[2] = { (int)(int8_t)((v >> 8) & 0xff), (int)v >> 24 };
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int c = 2 * w + h;  // sample index relative to 40*tid + 6
+#pragma unroll
+			for (int o = 0; o < 4; o++) {
+				const int n = c - 10 * o;
+				if (n >= 0 && n < 60) {
+					acc_i[o] += (xi[h] * kTaps10[n]) >> 10;
+					acc_q[o] += (xq[h] * kTaps10[n]) >> 10;
+				}
+			}
+		}
+	}
+	uint32_t ow[4];
+#pragma unroll
+	for (int o = 0; o < 4; o++)
+		ow[o] = ((uint32_t)(int16_t)acc_i[o] & 0xffffu) | ((uint32_t)(int16_t)acc_q[o] << 16);
+	*reinterpret_cast<uint4 *>(out + (size_t)s * out_stride + m0 + 4 * tid) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
+hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
+			  const uint8_t *tail_in, uint8_t *tail_out, uint32_t *out, size_t out_stride)
+{
+	const long n_out = (long)n_blocks * (TFREC_AMD_BLOCK_BYTES / 2);  // complex samples at 1.536 MS/s
+	dim3 grid((unsigned)(n_out / kT10), n_streams);
+	hipLaunchKernelGGL(decim10_kernel, grid, dim3(256), 0, st, iq, stride, n_out, tail_in, tail_out, out, out_stride);
+	return hipGetLastError();
+}
+
 hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
 			   unsigned long long *mask, size_t mask_stride, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			   int thresh, const FrontTaps &taps)
+			   int thresh, const FrontTaps &taps, bool in16)
 {
 	const int m_total = n_blocks * kBlockDec;
 	dim3 grid(m_total / kTileDec, n_streams);
-	hipLaunchKernelGGL(frontend_kernel, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out, dec,
-			   dec_stride, mask, mask_stride, fmdev, fmdev_stride, eb, thresh, taps);
+	if (in16)
+		hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out,
+				   dec, dec_stride, mask, mask_stride, fmdev, fmdev_stride, eb, thresh, taps);
+	else
+		hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out,
+				   dec, dec_stride, mask, mask_stride, fmdev, fmdev_stride, eb, thresh, taps);
 	return hipGetLastError();
 }
 

@@ -50,6 +50,9 @@ def _load():
         lib.iqgen_stream.restype = C.c_int
         lib.iqgen_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.POINTER(Truth), C.c_int]
+        lib.iqgen_stream_rate.restype = C.c_int
+        lib.iqgen_stream_rate.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.POINTER(Truth), C.c_int, C.c_int]
         lib.iqgen_batch.restype = C.c_int
         lib.iqgen_batch.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib = lib
@@ -57,13 +60,14 @@ def _load():
 
 
 def gen_stream(seed: int, stream: int, n_blocks: int, proto_mask: int = 0x1F, noise_q8: int = 256,
-               with_truth: bool = False):
-    """One stream of ``n_blocks`` 65536-byte blocks -> uint8 array (and the planted bursts)."""
+               with_truth: bool = False, rate_mult: int = 1):
+    """One stream of ``n_blocks`` blocks of 65536*rate_mult bytes -> uint8 array (and the planted bursts).
+    rate_mult 10 = the 15.36 MS/s input of BASELINE config 5."""
     lib = _load()
-    out = np.empty(n_blocks * BLOCK_BYTES, dtype=np.uint8)
+    out = np.empty(n_blocks * BLOCK_BYTES * rate_mult, dtype=np.uint8)
     cap = 4096
     truth = (Truth * cap)()
-    n = lib.iqgen_stream(seed, stream, n_blocks, proto_mask, noise_q8, out.ctypes.data, truth, cap)
+    n = lib.iqgen_stream_rate(seed, stream, n_blocks, proto_mask, noise_q8, out.ctypes.data, truth, cap, rate_mult)
     if not with_truth:
         return out
     recs = []

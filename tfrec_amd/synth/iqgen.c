@@ -17,7 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define FS 1536000
+#define FS_BASE 1536000
 #define BLOCK_SAMPLES 32768
 
 typedef struct {
@@ -251,8 +251,9 @@ static const int baud_tab[5] = { 38400, 17240, 9600, 8842, 6000 };
 
 /* returns burst length in samples; writes Q16 signal into si/sq[start..start+len) */
 static int64_t synth_burst(rng_t *r, work_t *w, int proto, int64_t start, int64_t total, int32_t *si, int32_t *sq,
-			   iqgen_truth_t *tr)
+			   iqgen_truth_t *tr, int64_t fs)
 {
+	const int64_t FS = fs;
 	uint8_t frame[64];
 	uint8_t bits[1024];
 	size_t nb = 0;
@@ -370,34 +371,38 @@ static void quantise(rng_t *r, const int32_t *si, const int32_t *sq, int64_t n, 
 	}
 }
 
-/* Generate one stream of n_blocks*65536 bytes.  proto_mask: bit p enables protocol p (0..4).
- * noise_q8: noise sigma in 1/256 LSB (256 = 1.0 LSB).  Returns the number of planted bursts. */
-int iqgen_stream(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, int noise_q8, uint8_t *out,
-		 iqgen_truth_t *truth, int truth_cap)
+/* Generate one stream of n_blocks*65536*rate_mult bytes at rate_mult * 1.536 MS/s (rate_mult 1: what an RTL-SDR
+ * delivers; 10: the 15.36 MS/s input of BASELINE config 5 -- same recipe, every duration in samples scaled).
+ * proto_mask: bit p enables protocol p (0..4).  noise_q8: noise sigma in 1/256 LSB (256 = 1.0 LSB).  Returns the
+ * number of planted bursts. */
+int iqgen_stream_rate(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, int noise_q8, uint8_t *out,
+		      iqgen_truth_t *truth, int truth_cap, int rate_mult)
 {
 	rng_t r, rn;
 	rng_seed(&r, seed, stream);
 	rng_seed(&rn, seed ^ 0x5851F42D4C957F2DULL, stream);
-	int64_t total = (int64_t)n_blocks * BLOCK_SAMPLES;
+	const int64_t fs = (int64_t)FS_BASE * rate_mult;
+	const int64_t block_samples = (int64_t)BLOCK_SAMPLES * rate_mult;
+	int64_t total = (int64_t)n_blocks * block_samples;
 	int32_t *si = (int32_t *)calloc((size_t)total, sizeof(int32_t));
 	int32_t *sq = (int32_t *)calloc((size_t)total, sizeof(int32_t));
 	work_t w = { 0, 0, 0 };
 	int nt = 0;
-	int64_t pos = 40000;
+	int64_t pos = 40000 * (int64_t)rate_mult;
 	int proto = (int)(stream % 5);
-	int64_t limit = total - BLOCK_SAMPLES - 4096; /* keep the last block silent so windows time out */
+	int64_t limit = total - block_samples - 4096 * (int64_t)rate_mult; /* keep the last block silent so windows time out */
 	if (proto_mask & 0x1f) {
 		while (pos < limit) {
 			while (!(proto_mask & (1 << proto)))
 				proto = (proto + 1) % 5;
 			iqgen_truth_t tr;
-			int64_t len = synth_burst(&r, &w, proto, pos, limit, si, sq, &tr);
+			int64_t len = synth_burst(&r, &w, proto, pos, limit, si, sq, &tr, fs);
 			if (len < 0)
 				break;
 			if (truth && nt < truth_cap)
 				truth[nt] = tr;
 			nt++;
-			pos += len + rng_range(&r, 20000, 60000);
+			pos += len + (int64_t)rng_range(&r, 20000, 60000) * rate_mult;
 			proto = (proto + 1) % 5;
 		}
 	}
@@ -407,6 +412,12 @@ int iqgen_stream(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, i
 	free(w.lvl);
 	free(w.tmp);
 	return nt;
+}
+
+int iqgen_stream(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, int noise_q8, uint8_t *out,
+		 iqgen_truth_t *truth, int truth_cap)
+{
+	return iqgen_stream_rate(seed, stream, n_blocks, proto_mask, noise_q8, out, truth, truth_cap, 1);
 }
 
 /* Batch: streams first_stream .. first_stream+n_streams-1, contiguous in out. OpenMP over streams. */
