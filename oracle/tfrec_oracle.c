@@ -23,6 +23,11 @@
  *
  * Members the reference leaves uninitialised (last_i/last_q of every demodulator, whb avg_of, rdata;
  * tfa1.cpp:136-141, tfa2.cpp:316-323, whb.cpp:605-614) are defined as 0 here, as in ref_driver.
+ *
+ * One stage here has NO reference counterpart and is therefore "parity unpinned": orc_decim10, the 10:1 front
+ * end of BASELINE config 5 (15.36 MS/s input), which this project defines itself in the reference's FIR style.
+ * Its output is pinned only as a hash of this restatement's own result (tests/golden/config5.json); everything
+ * it feeds (orc_process_s16) is pinned by the real reference through its int16 entry (ref_driver run16).
  */
 #define _GNU_SOURCE
 #include "tfrec_oracle.h"

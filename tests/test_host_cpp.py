@@ -68,3 +68,41 @@ def test_dump_replay_cli_matches_reference_text(cli, golden_dir, tmp_path):
     out2 = subprocess.run([cli, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-L", str(p), "-L", str(p2)],
                           capture_output=True, text=True, check=True).stdout
     assert len([ln for ln in out2.splitlines() if ln.strip()]) >= len(want)
+
+
+def test_batched_sink_and_per_record_handler(cli, tmp_path):
+    """SURVEY row f4: -E starts the handler once and feeds it '<stream> <reference handler args>' lines on stdin;
+    -e keeps the reference's one-exec-per-record contract (decoder.cpp:67-96)."""
+    f = tmp_path / "kat.txt"
+    f.write_text("# README.md:123\n2d d4 65 b0 86 20 23 60 e0 56 97\n2d d4 65 b0 86 20 23 60 e0 56 97\n")
+    sink = tmp_path / "sink.out"
+    subprocess.run([cli, "-T", "1", "-q", "-X", str(f), "-E", "cat > %s" % sink], check=True)
+    lines = sink.read_text().splitlines()
+    assert len(lines) == 2  # (the -X entry uses a fresh flush per line: both records are delivered)
+    for ln in lines:
+        p = ln.split()
+        assert p[:8] == ["0", "65b0", "+22.0", "35", "14", "0", "0", "0"] and int(p[8]) > 0
+    out = subprocess.run([cli, "-T", "1", "-q", "-X", str(f), "-e", "echo REC"], capture_output=True, text=True,
+                         check=True).stdout
+    recs = [ln.split() for ln in out.splitlines() if ln.startswith("REC")]
+    assert len(recs) == 2 and recs[0][1:8] == ["65b0", "+22.0", "35", "14", "0", "0", "0"]
+
+
+@pytest.mark.gpu
+def test_batched_sink_on_dump_replay(cli, golden_dir, tmp_path):
+    from tfrec_amd import synth
+    cases = json.load(open(os.path.join(golden_dir, "streams.json")))["cases"]
+    c = cases[0]
+    files = []
+    for k in range(3):  # three streams in one batch: records carry their stream index
+        iq = synth.gen_stream(c["seed"], c["stream"] + k, c["n_blocks"], c["proto_mask"], c["noise_q8"])
+        p = tmp_path / ("s%d.iq" % k)
+        iq.tofile(p)
+        files += ["-L", str(p)]
+    sink = tmp_path / "sink.out"
+    out = subprocess.run([cli, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-b", "16", "-E", "cat > %s" % sink] + files,
+                         capture_output=True, text=True, check=True).stdout
+    recs = [ln.split() for ln in sink.read_text().splitlines()]
+    assert len(recs) >= 20 and {r[0] for r in recs} == {"0", "1", "2"}
+    # every record corresponds to a printed telegram (TX22 / WHB telegrams expand to several records)
+    assert len(recs) >= len([ln for ln in out.splitlines() if ln.strip()])

@@ -13,7 +13,7 @@
 gpu_engine::gpu_engine(const std::vector<std::string> &dumpfiles, int _types, int _thresh, int _filter, int _dbg,
 		       int _device, int blocks_per_submit)
 	: files(dumpfiles), types(_types), thresh(_thresh), filter(_filter), dbg(_dbg), device(_device),
-	  bps(blocks_per_submit), n_telegrams(0)
+	  bps(blocks_per_submit), n_telegrams(0), sink(NULL), out_mode(0)
 {
 	// one set of protocol handlers per stream, registered like main.cpp:173-218
 	for (size_t s = 0; s < files.size(); s++) {
@@ -30,8 +30,55 @@ gpu_engine::gpu_engine(const std::vector<std::string> &dumpfiles, int _types, in
 	}
 }
 
+pipe_sink::pipe_sink(const char *command) : pipe(popen(command, "w")), n_records(0)
+{
+	if (!pipe)
+		perror(command);
+}
+
+pipe_sink::~pipe_sink()
+{
+	flush();
+	if (pipe)
+		pclose(pipe);
+}
+
+void pipe_sink::put(int stream, const char *args)
+{
+	char head[32];
+	snprintf(head, sizeof(head), "%d ", stream);
+	pending += head;
+	pending += args;
+	pending += '\n';
+	n_records++;
+}
+
+void pipe_sink::flush()
+{
+	if (pipe && !pending.empty()) {
+		fwrite(pending.data(), 1, pending.size(), pipe);
+		fflush(pipe);
+	}
+	pending.clear();
+}
+
+void gpu_engine::set_handler(const char *exec, bool batched, int mode)
+{
+	out_mode = mode;
+	if (batched && exec && *exec)
+		sink = new pipe_sink(exec);
+	for (size_t s = 0; s < decs.size(); s++)
+		for (size_t k = 0; k < decs[s].size(); k++)
+			if (decs[s][k]) {
+				decs[s][k]->set_params(batched ? NULL : (char *)exec, mode, dbg);
+				if (sink)
+					decs[s][k]->set_sink(sink, (int)s);
+			}
+}
+
 gpu_engine::~gpu_engine()
 {
+	delete sink;
 	for (size_t s = 0; s < decs.size(); s++)
 		for (size_t k = 0; k < decs[s].size(); k++)
 			delete decs[s][k];
@@ -166,7 +213,16 @@ int gpu_engine::run()
 		for (int q = 0; q < nev; q++)
 			if (ev[q].end_sample < stream_samples[ev[q].stream])
 				replay(ev[q]);
+		if (sink)
+			sink->flush();  // the records of the whole batch in one write
 	}
+	if (out_mode)  // -m 1: summary at the end (decoder.cpp:98-109)
+		for (size_t s = 0; s < decs.size(); s++)
+			for (size_t k2 = 0; k2 < decs[s].size(); k2++)
+				if (decs[s][k2])
+					decs[s][k2]->flush_storage();
+	if (sink)
+		sink->flush();
 	if (rc)
 		fprintf(stderr, "tfrec_amd: %s (%s)\n", tfrec_amd_strerror(rc), tfrec_amd_last_error());
 	{

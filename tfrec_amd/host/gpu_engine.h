@@ -8,11 +8,30 @@
 #ifndef TFREC_AMD_HOST_GPU_ENGINE_H
 #define TFREC_AMD_HOST_GPU_ENGINE_H
 
+#include <stdio.h>
+
 #include <string>
 #include <vector>
 
 #include "../../include/tfrec_amd.h"
 #include "plugin.h"
+
+// One long-lived handler process for ALL streams: records go to its stdin, one line each,
+// "<stream> <id> <temp> <hum> <seq> <alarm> <rssi> <flags> <ts>" -- the reference's handler arguments
+// (decoder.cpp:67-96) prefixed with the stream index -- written once per batch.
+class pipe_sink : public batch_sink {
+public:
+	explicit pipe_sink(const char *command);
+	~pipe_sink();
+	void put(int stream, const char *args);
+	void flush();
+	long records() const { return n_records; }
+
+private:
+	FILE *pipe;
+	std::string pending;
+	long n_records;
+};
 
 class gpu_engine {
 public:
@@ -20,6 +39,9 @@ public:
 	gpu_engine(const std::vector<std::string> &dumpfiles, int types, int thresh, int filter, int dbg, int device,
 		   int blocks_per_submit);
 	~gpu_engine();
+	// exec: per-telegram handler as the reference's -e (system() per record); batched: the same command started
+	// once, records on its stdin (pipe_sink); mode: the reference's -m (1 = summary at the end)
+	void set_handler(const char *exec, bool batched, int mode);
 	// returns 0 on success, a TFREC_AMD_E_* code otherwise
 	int run();
 	// decoders of stream s in slot order (NULL for slots not registered)
@@ -33,6 +55,8 @@ private:
 	std::vector<std::vector<decoder *> > decs;
 	std::vector<long long> stream_samples;  // decimated samples each file really holds
 	long n_telegrams;
+	pipe_sink *sink;
+	int out_mode;
 };
 
 #endif

@@ -1,12 +1,16 @@
 // tfrec_amd/host/main.cpp -- tfrec_gpu: the reference's file-replay CLI on the GPU path.
 //
-//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d device] [-b blocks] -L dump.iq [-L more.iq ...]
+//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d device] [-b blocks] [-e handler | -E handler] [-m mode]
+//             -L dump.iq [-L more.iq ...]
 //   tfrec_gpu [-T hexmask] -X telegrams.txt
 //
 // Flags keep the reference's meaning (main.cpp:63-88, 107-164): -T sensor type bit mask (hex), -t trigger
 // threshold (0 = auto, the default), -W wide filter, -q quiet, -D debug,
+// -e handler executed for every message, -m 1 summary at exit,
 // -L raw 8-bit IQ dump as written by "tfrec -S", -X hex telegrams for the byte-level test entry
 // (main.cpp:24-53).  Several -L files are processed as one batch, one stream each.
+// -E handler (not in the reference): the handler is started ONCE and receives the records of all
+// streams on stdin, "<stream> <id> <temp> <hum> <seq> <alarm> <rssi> <flags> <ts>" per line, one write per batch.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,8 +21,9 @@
 
 #include "gpu_engine.h"
 
-static int replay_hex(int types, int dbg, const char *fn)
+static int replay_hex(int types, int dbg, const char *fn, const char *exec, bool batched)
 {
+	pipe_sink *sink = (batched && exec) ? new pipe_sink(exec) : NULL;
 	std::vector<decoder *> decs;
 	if (types & (1 << TFA_1)) decs.push_back(new tfa1_decoder(TFA_1));
 	if (types & (1 << TFA_2)) decs.push_back(new tfa2_decoder(TFA_2));
@@ -39,7 +44,9 @@ static int replay_hex(int types, int dbg, const char *fn)
 		for (char *tok = strtok(line, " \t\r\n"); tok && len < (int)sizeof(buf); tok = strtok(NULL, " \t\r\n"))
 			buf[len++] = (uint8_t)strtol(tok, NULL, 16);
 		for (size_t k = 0; k < decs.size(); k++) {
-			decs[k]->set_params(NULL, 0, dbg);
+			decs[k]->set_params(batched ? NULL : (char *)exec, 0, dbg);
+			if (sink)
+				decs[k]->set_sink(sink, 0);
 			decs[k]->store_bytes(buf, len);
 			decs[k]->flush(0);
 			puts("");
@@ -47,6 +54,7 @@ static int replay_hex(int types, int dbg, const char *fn)
 		}
 	}
 	fclose(fd);
+	delete sink;  // flushes
 	return 0;
 }
 
@@ -54,9 +62,11 @@ int main(int argc, char **argv)
 {
 	int types = 0x07, thresh = 0, filter = 0, dbg = 0, device = 0, blocks = 16;  // defaults of main.cpp:97-105 (0 = auto)
 	std::vector<std::string> dumps;
-	const char *hexfile = NULL;
+	const char *hexfile = NULL, *exec = NULL;
+	bool batched = false;
+	int mode = 0;
 	int c;
-	while ((c = getopt(argc, argv, "T:t:WqDd:b:L:X:h")) != -1) {
+	while ((c = getopt(argc, argv, "T:t:WqDd:b:L:X:e:E:m:h")) != -1) {
 		switch (c) {
 		case 'T': types = (int)strtol(optarg, NULL, 16); break;
 		case 't': thresh = atoi(optarg); break;
@@ -67,6 +77,9 @@ int main(int argc, char **argv)
 		case 'b': blocks = atoi(optarg); break;
 		case 'L': dumps.push_back(optarg); break;
 		case 'X': hexfile = optarg; break;
+		case 'e': exec = optarg; batched = false; break;
+		case 'E': exec = optarg; batched = true; break;
+		case 'm': mode = atoi(optarg); break;
 		default:
 			fprintf(stderr, "usage: tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d dev] [-b blocks] -L dump [-L dump ...] | -X hexfile\n");
 			return c == 'h' ? 0 : 1;
@@ -74,7 +87,7 @@ int main(int argc, char **argv)
 	}
 	setvbuf(stdout, NULL, _IOFBF, 1 << 16);
 	if (hexfile)
-		return replay_hex(types, dbg, hexfile);
+		return replay_hex(types, dbg, hexfile, exec, batched);
 	if (dumps.empty()) {
 		fprintf(stderr, "tfrec_gpu: need -L <dumpfile> or -X <hexfile>\n");
 		return 1;
@@ -84,6 +97,8 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	gpu_engine e(dumps, types, thresh, filter, dbg, device, blocks);
+	if (exec || mode)
+		e.set_handler(exec, batched, mode);
 	int rc = e.run();
 	fflush(stdout);
 	return rc ? 2 : 0;

@@ -39,6 +39,16 @@ typedef struct {
 	int rssi;
 } sensordata_t;
 
+// Batched result sink.  The reference runs system("<handler> <args>") once per telegram
+// (decoder.cpp:67-96): one fork+exec per record does not scale to thousands of streams.  A decoder that has a sink
+// hands the SAME argument string (id temp hum seq alarm rssi flags ts) to it instead, tagged with its stream; the
+// engine flushes the sink once per batch (gpu_engine.cpp: one long-lived handler process fed through a pipe).
+class batch_sink {
+public:
+	virtual ~batch_sink() {}
+	virtual void put(int stream, const char *args) = 0;
+};
+
 // decoder.h:33-59
 class decoder {
 public:
@@ -54,6 +64,8 @@ public:
 	int count(void) { return (int)data.size(); }
 	sensor_e get_type(void) { return type; }
 	virtual void store_bytes(uint8_t *d, int len);
+	// not in the reference: route execute_handler() to a batch sink (records are tagged with `stream`)
+	void set_sink(batch_sink *s, int stream) { sink = s; sink_stream = stream; }
 
 protected:
 	int dbg;
@@ -67,6 +79,8 @@ private:
 	char *handler;
 	int mode;
 	std::map<uint64_t, sensordata_t> data;
+	batch_sink *sink;
+	int sink_stream;
 };
 
 // decoder.h:61-73.  On the GPU path the demodulators run in HIP; this class only keeps the (decoder*)
