@@ -543,9 +543,10 @@ __device__ __forceinline__ BiquadEnd end_of(const Biquad &f)
 	return e;
 }
 
-// K3a (repair = 0) and K3b (repair = 1); whb: 0 = TFA_2-family chains, 1 = WHB chains (one kind per launch)
+// K3a (repair = 0), K3b (repair = 1) and K3b' (repair = 2: segments whose predecessor's repair run did not
+// converge are run once more, from THAT run's end state); whb: 0 = TFA_2-family chains, 1 = WHB chains
 template <bool WHB>
-__device__ __forceinline__ void seg_task(uint2 it, bool repair, int n_streams, int M, const uint32_t *__restrict__ dec,
+__device__ __forceinline__ void seg_task(uint2 it, int repair, int n_streams, int M, const uint32_t *__restrict__ dec,
 					 size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
 					 const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
 					 int32_t *__restrict__ dev32)
@@ -570,14 +571,29 @@ __device__ __forceinline__ void seg_task(uint2 it, bool repair, int n_streams, i
 			f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
 		(void)seg_run<WHB, false>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
 		T.segend1[sk] = end_of(f);
-	} else if (k > 0) {
-		f = biquad_of(T.segend1[sk - 1]);
-		const int done = seg_run<WHB, true>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
-		T.segfix[sk] = done | (conv ? kSegConverged : 0);
-		if (!conv) {
-			T.segend2[sk] = end_of(f);
-			atomicAdd(&T.stats[1], 1ull);
+	} else if (repair == 1) {
+		if (k > 0) {
+			f = biquad_of(T.segend1[sk - 1]);
+			const int done = seg_run<WHB, true>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
+			T.segfix[sk] = done | (conv ? kSegConverged : 0);
+			if (!conv) {
+				T.segend2[sk] = end_of(f);
+				atomicAdd(&T.stats[1], 1ull);
+			}
 		}
+	} else {
+		int fx2 = 0;
+		if (k > 1 && !(T.segfix[sk - 1] & kSegConverged)) {
+			// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
+			// the true one, its end state segend2[k-1] is where segment k really starts
+			f = biquad_of(T.segend2[sk - 1]);
+			const int done = seg_run<WHB, true>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots,
+							    T.segfix[sk] & ~kSegConverged, conv);
+			fx2 = done | (conv ? kSegConverged : 0) | kSegRan;
+			if (!conv)
+				T.segend3[sk] = end_of(f);
+		}
+		T.segfix2[sk] = fx2;
 	}
 }
 
@@ -592,16 +608,16 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int q = 4 + 2 * whb;
 	const uint32_t count = T.queue[q].count;
-	uint32_t *head = repair ? &T.queue[q].head2 : &T.queue[q].head;
+	uint32_t *head = repair == 0 ? &T.queue[q].head : (repair == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
 	while (true) {
 		const uint32_t idx = atomicAdd(head, 1u);
 		if (idx >= count)
 			break;
 		const uint2 it = T.items[(size_t)q * total + idx];
 		if (whb)
-			seg_task<true>(it, repair != 0, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+			seg_task<true>(it, repair, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 		else
-			seg_task<false>(it, repair != 0, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+			seg_task<false>(it, repair, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 	}
 }
 
@@ -641,23 +657,27 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 			if (k >= nseg)
 				break;
 			cur = e1[k];
-			const int fx = T.segfix[(size_t)c * T.segcap + k];
-			if (same_bits(f.yn, prev.yn) && same_bits(f.yn1, prev.yn1) && same_bits(f.dn1, prev.dn1) &&
-			    same_bits(f.dn2, prev.dn2)) {
-				// K3b ran segment k from the true state: what is stored now is the true trajectory
-				f = biquad_of((fx & kSegConverged) ? cur : T.segend2[(size_t)c * T.segcap + k]);
+			const size_t sk = (size_t)c * T.segcap + k;
+			const int fx2 = T.segfix2[sk];
+			const bool second = (fx2 & kSegRan) != 0;  // the LAST run that wrote segment k: K3b' or K3b
+			const int fx = second ? fx2 : T.segfix[sk];
+			const BiquadEnd from = second ? T.segend2[sk - 1] : prev;  // the state that run started from
+			if (same_bits(f.yn, from.yn) && same_bits(f.yn1, from.yn1) && same_bits(f.dn1, from.dn1) &&
+			    same_bits(f.dn2, from.dn2)) {
+				// it ran segment k from the true state: what is stored now is the true trajectory
+				f = biquad_of((fx & kSegConverged) ? cur : (second ? T.segend3[sk] : T.segend2[sk]));
 				prev = cur;
 				k++;
 				continue;
 			}
-			// K3b started from a wrong state: repair serially from f, at least as far as K3b had written
+			// it started from a wrong state: repair serially from f, at least as far as it had written
 			atomicAdd(&T.stats[2], 1ull);
 			const uint2 start = T.segstart[(size_t)c * T.segcap + k];
 			j = (int)start.x;
 			i = (int)start.y;
 			const int left = vtotal - k * kSegSlots;
 			nslots = left < kSegSlots ? left : kSegSlots;
-			min_slots = fx & ~kSegConverged;
+			min_slots = fx & ~(kSegConverged | kSegRan);
 			done = 0;
 			nsamples = 0;
 			cw = seg_win(T, c, j, M);
@@ -2205,6 +2225,8 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		mark(10, ws);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 1);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 2);
 		mark(11, ws);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 2);
@@ -2229,6 +2251,8 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		mark(2, st);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 2);
 		mark(3, st);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 1);

@@ -133,7 +133,7 @@ struct WorkQueue {
 	uint32_t count;  // items pushed
 	uint32_t head;   // items taken
 	uint32_t head2;  // items taken by a second pass over the same queue
-	uint32_t pad_;
+	uint32_t head3;  // ... and by a third
 };
 
 struct WinTables {
@@ -162,13 +162,15 @@ struct WinTables {
 	BiquadEnd *segend1;     // [chains*segcap] state after the segment, speculative run
 	BiquadEnd *segend2;     // [chains*segcap] state after the segment, repair run that did not converge
 	int32_t *segfix;        // [chains*segcap] repair run: slots rewritten | kSegConverged
+	BiquadEnd *segend3;     // [chains*segcap] ... second repair run (started from segend2 of the segment before)
+	int32_t *segfix2;       // [chains*segcap] second repair run: slots rewritten | kSegConverged | kSegRan (0: not run)
 	int32_t *overflow;      // set when a chain found more than cap windows
 	unsigned long long *stats;  // [8] tfrec_amd_stats
 };
 
 constexpr int kNQueues = 8;
 constexpr int kSegSlots = 128;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
-constexpr int kSegConverged = 0x40000000;
+constexpr int kSegConverged = 0x40000000, kSegRan = 0x20000000;
 constexpr int kLongWindow = 2048;  // samples; longer windows go to the wave-cooperative slicers (default)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
