@@ -376,6 +376,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_sstart = carve(segs * sizeof(uint2)), o_vtotal = carve(chains * 4);
 		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
 		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4);
+		const size_t o_cand = carve(n * (size_t)T.slots * 4), o_mark = carve(n * (size_t)T.slots * sizeof(MarkPiece));
 		ALLOC(c->win_block, off);
 		if (rc == TFREC_AMD_OK) {
 			uint8_t *b = (uint8_t *)c->win_block;
@@ -400,6 +401,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.segfix = (int32_t *)(b + o_sfix);
 			T.segend3 = (BiquadEnd *)(b + o_se3);
 			T.segfix2 = (int32_t *)(b + o_sfix2);
+			T.cand = (uint32_t *)(b + o_cand);
+			T.mark = (MarkPiece *)(b + o_mark);
 			if (hipMemset(T.queue, 0, kNQueues * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
 			    hipMemset(T.stats, 0, 64) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;

@@ -219,6 +219,9 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 				push(2 * kind + (n >= long_window ? 0 : 1), make_uint2((uint32_t)c, (uint32_t)count[a]));
 			if (kind == 2)
 				push(5, make_uint2((uint32_t)c, (uint32_t)count[a]));
+			if (kind == 0 && n >= long_window)  // peak-detector pieces of a long TFA_1 window
+				for (int pc = 0; pc * kMarkSlots * 32 < n; pc++)
+					push(7, make_uint2((uint32_t)c, (uint32_t)count[a] | ((uint32_t)pc << 17)));
 			if (kind > 0) {  // the chain owns a biquad: an item per segment that starts in this window; queue 4: TFA_2
 				         // family, 6: WHB
 				const int nch = (n + 31) >> 5;
@@ -1041,6 +1044,76 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ K4a' TFA_1 marks
+// The TFA_1 peak detector mark_lvl = dev > mark_lvl ? dev : (int)(mark_lvl * 0.95) (tfa1.cpp:157-160) is a serial
+// recurrence, but a forgetful one: at every sample with dev > mark_lvl the state becomes dev whatever it was.
+// Lane per PIECE of 1024 samples of a long window: the lane starts 256 samples early from mark_lvl = 0 (the
+// window's first piece from the true initial value), and stores for its piece the bits "dev < mark_lvl / 2"
+// (tfa1.cpp:164), the maximum (rssi) and the value before / after the piece.  coop_slicer_kernel checks
+// start == the true value bit for bit when it reaches the piece, and otherwise recomputes the piece itself:
+// exactness does not rest on the warm-up, only speed does.  16 lane-instructions per sample for 64 pieces at once
+// instead of 7 wave-instructions per sample.
+__global__ __launch_bounds__(64) void mark_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
+						  int n_blocks, ChainLaunch L, WinTables T)
+{
+	const int M = n_blocks * kBlockDec;
+	const size_t total = (size_t)L.n_active * n_streams * T.cap;
+	const uint32_t count = T.queue[7].count;
+	const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
+	for (uint32_t idx = tid; idx < count; idx += nthreads) {
+		const uint2 it = T.items[(size_t)7 * total + idx];
+		const int c = (int)it.x, j = (int)(it.y & 0x1ffffu), pc = (int)(it.y >> 17);
+		const int a = c / n_streams, s = c - a * n_streams;
+		const ChainState &st = L.states[a][s];
+		const int og = T.open[(size_t)c * T.cap + j];
+		const int close = T.close[(size_t)c * T.cap + j];
+		const int n = (close < M ? close : M - 1) - og + 1;
+		const uint32_t *drow = dec + (size_t)s * dec_stride;
+		const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
+		const int slot0 = win_slot0(og, j);
+		const int i0 = pc * kMarkSlots;                                          // first slot of the piece
+		const int nch = (n + 31) >> 5;
+		const int i1 = nch < i0 + kMarkSlots ? nch : i0 + kMarkSlots;
+		const int iw = pc == 0 ? 0 : i0 - kMarkWarmSlots;                      // warm-up start (pc >= 1: i0 >= 32)
+		int mark = (pc == 0 && j == 0 && T.cont[c]) ? st.mark_lvl : 0;
+		int start = mark, mx = 0;
+		K3Chunk<true> A, B;
+		k3_load<true>(A, drow, og + 32 * iw, prev0);
+		for (int i = iw; i < i1; i++) {
+			if (i + 1 < i1)
+				k3_load<true>(B, drow, og + 32 * (i + 1), prev0);
+			if (i == i0)
+				start = mark;
+			const int nv = n - 32 * i < 32 ? n - 32 * i : 32;
+			int pI = (int)(int16_t)(A.prevw & 0xffff), pQ = (int)A.prevw >> 16;
+			uint32_t bits = 0;
+#pragma unroll
+			for (int k = 0; k < 32; k++) {
+				const int I = (int)(int16_t)(A.w[k] & 0xffff), Q = (int)A.w[k] >> 16;
+				if (k < nv) {
+					const int dev = fm_dev_nrzs(I, Q, pI, pQ);
+					mark = dev > mark ? dev : (int)((double)mark * 0.95);  // mark >= 0: plain truncation
+					mx = mark > mx ? mark : mx;
+					bits |= (uint32_t)(dev < mark / 2) << k;
+				}
+				pI = I;
+				pQ = Q;
+			}
+			if (i >= i0)
+				T.cand[(size_t)s * T.slots + slot0 + i] = bits;
+			else
+				mx = 0;  // the warm-up does not count
+			A = B;
+		}
+		MarkPiece mp;
+		mp.start = start;
+		mp.end = mark;
+		mp.max = mx;
+		mp.pad_ = 0;
+		T.mark[(size_t)s * T.slots + slot0 + i0] = mp;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------ K4b
 // Wave-cooperative slicers for LONG windows: one wave per window, lane n owns sample n of a 64-sample step.
 // A lane-per-window slicer needs ~100 instructions per sample on a serial path; a 40 000-sample burst then
@@ -1280,27 +1353,47 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 		v.y = g > 0 ? drow[g - 1] : prev0;
 		return v;
 	};
-	uint2 nxt = load(og + lane <= last ? og + lane : last);
+	// mark_kernel has run the peak detector of every 1024-sample piece from a warm-up: its result is used when the
+	// value it started the piece from is the true one, otherwise the piece is recomputed here (wave-uniform)
+	const int slot0 = win_slot0(og, j);
+	const uint32_t *candrow = T.cand + (size_t)s * T.slots + slot0;
+	const MarkPiece *markrow = T.mark + (size_t)s * T.slots + slot0;
+	bool piece_ok = false;
+	MarkPiece mp = { 0, 0, 0, 0 };
 	for (int gb = og; gb <= last; gb += 64) {
-		const uint2 cur = nxt;
-		if (gb + 64 <= last)
-			nxt = load(gb + 64 + lane <= last ? gb + 64 + lane : last);
-		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
-		const int dev = fm_dev_nrzs((int)(int16_t)(cur.x & 0xffff), (int)cur.x >> 16, (int)(int16_t)(cur.y & 0xffff),
-					    (int)cur.y >> 16);
-		// the peak detector, wave-uniform (tfa1.cpp:157-160); mark >= 0 always, so (int) truncation is exact
-		for (int k = 0; k < nv; k++) {
-			const int dk = __builtin_amdgcn_readlane(dev, k);
-			mark = dk > mark ? dk : (int)((double)mark * 0.95);
-			lds_m[k] = mark;
+		const int step = (gb - og) >> 6;  // two slots per step, kMarkSlots / 2 steps per piece
+		if ((step & (kMarkSlots / 2 - 1)) == 0) {
+			mp = markrow[2 * step];
+			piece_ok = mp.start == mark;
+			if (piece_ok && mp.max > rssi_lane)
+				rssi_lane = mp.max;  // tfa1.cpp:161-162
 		}
-		__syncthreads();
-		const int mk = lds_m[lane];
-		__syncthreads();
-		const bool valid = lane < nv;
-		if (valid && mk > rssi_lane)
-			rssi_lane = mk;  // tfa1.cpp:161-162
-		unsigned long long m = __ballot(valid && dev < mk / 2);  // tfa1.cpp:164
+		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
+		unsigned long long m;
+		if (piece_ok) {
+			const unsigned long long lo = candrow[2 * step], hi = nv > 32 ? candrow[2 * step + 1] : 0u;
+			m = lo | (hi << 32);
+			if (gb + 64 > last || ((step + 1) & (kMarkSlots / 2 - 1)) == 0)
+				mark = mp.end;  // the piece ends with this step
+		} else {
+			const uint2 cur = load(gb + lane <= last ? gb + lane : last);
+			const int dev = fm_dev_nrzs((int)(int16_t)(cur.x & 0xffff), (int)cur.x >> 16, (int)(int16_t)(cur.y & 0xffff),
+						    (int)cur.y >> 16);
+			// the peak detector, wave-uniform (tfa1.cpp:157-160); mark >= 0 always, so (int) truncation is exact
+			for (int k = 0; k < nv; k++) {
+				const int dk = __builtin_amdgcn_readlane(dev, k);
+				mark = dk > mark ? dk : (int)((double)mark * 0.95);
+				lds_m[k] = mark;
+			}
+			__syncthreads();
+			const int mk = lds_m[lane];
+			__syncthreads();
+			const bool valid = lane < nv;
+			if (valid && mk > rssi_lane)
+				rssi_lane = mk;  // tfa1.cpp:161-162
+			m = __ballot(valid && dev < mk / 2);  // tfa1.cpp:164
+			atomicAdd(&T.stats[4], lane == 0 ? 1ull : 0ull);  // steps recomputed (tfrec_amd_get_stats)
+		}
 		while (m) {
 			const int k0 = __builtin_ctzll(m);
 			const unsigned long long inv = ~(m >> k0);
@@ -2264,6 +2357,9 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 48));
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
+		if (kind == 0)
+			hipLaunchKernelGGL(mark_kernel, dim3(std::max(1, win_blocks / 4)), block, 0, s_, dec, dec_stride, n_streams,
+					   n_blocks, L, T);
 		hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
 				   lanes_win, head_chunks, kind);
 		mark(m0 + 1, s_);

@@ -124,6 +124,17 @@ struct WhbStart {
 	int32_t pad_[3];
 };
 
+// TFA_1 peak detector (tfa1.cpp:157-160) over one piece of kMarkSlots slots of a long window, run by mark_kernel
+// from a warm-up (the detector forgets its state at every new peak): valid iff start == the true value
+struct MarkPiece {
+	int32_t start;  // mark_lvl before the piece's first sample, as the warm-up produced it
+	int32_t end;    // mark_lvl after the piece's last sample
+	int32_t max;    // max of mark_lvl over the piece (rssi, tfa1.cpp:161-162)
+	int32_t pad_;
+};
+constexpr int kMarkSlots = 32;   // 1024 samples per piece
+constexpr int kMarkWarmSlots = 8;  // 256 samples of warm-up
+
 // full biquad state at the end of a window (speculative or repaired run)
 struct BiquadEnd {
 	double dn1, dn2, yn, yn1;
@@ -147,10 +158,12 @@ struct WinTables {
 	WinResult *result;      // [chains*cap]
 	WinDecode *decode;      // [chains*cap]
 	WhbStart *whbstart;     // [n_streams*cap]
+	uint32_t *cand;         // [n_streams*slots] TFA_1 long windows: "dev < mark_lvl/2" bits of the slot's samples
+	MarkPiece *mark;        // [n_streams*slots] indexed by the piece's first slot
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
 	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
 	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment); queue 5: WHB
-	                        // windows (chain, j)
+	                        // windows (chain, j); queue 7: peak-detector pieces of long TFA_1 windows (chain, j | p << 17)
 	WorkQueue *queue;       // [8]
 	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
 	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
