@@ -2299,7 +2299,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	bool forked = false, t1_forked = false, has_tfa1 = false;
 	for (int a = 0; a < L.n_active; a++)
 		has_tfa1 = has_tfa1 || L.params[a].kind == 0;
-	if (t1 && has_tfa1 && has_tfa2) {  // TFA_1 needs no biquad stage: its slicers start right after the window scan
+	if (t1 && has_tfa1 && has_tfa2 && env_int("TFREC_AMD_T1_EARLY", 0)) {
 		if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(t1, ev_fork, 0)) != hipSuccess)
 			return e;
 		t1_forked = true;
@@ -2342,6 +2342,13 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);
 		mark(2, st);
+		if (t1 && has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
+			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad passes (on the
+			// critical path of the two other chains) have had the chip to themselves
+			if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(t1, ev_fork, 0)) != hipSuccess)
+				return e;
+			t1_forked = true;
+		}
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
