@@ -14,8 +14,11 @@ hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int 
 			  const uint8_t *tail_in, uint8_t *tail_out, uint32_t *out, size_t out_stride);
 hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
-			   unsigned long long *mask, size_t mask_stride, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			   int thresh, const FrontTaps &taps, bool in16);
+			   unsigned long long *mask, size_t mask_stride, uint32_t *prevdec, int thresh, const FrontTaps &taps,
+			   bool in16);
+hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
+			int n_streams, int n_blocks, int wmax);
 hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
@@ -54,7 +57,9 @@ struct tfrec_amd_ctx {
 	size_t dec_stride = 0;  // uint32 units
 	unsigned long long *d_mask[2] = { nullptr, nullptr };
 	size_t mask_stride = 0;
-	int16_t *d_fmdev[2] = { nullptr, nullptr };  // [n_streams][m_max] fm_dev of every decimated sample
+	int16_t *d_fmdev[2] = { nullptr, nullptr };  // [n_streams][m_max] fm_dev of the decimated samples (computed near windows)
+	uint32_t *d_prevdec[2] = { nullptr, nullptr };  // [n_streams] the decimated sample before the submit's first one
+	bool need_fmdev = false;                      // a TFA_2-family demodulator is registered
 	// Few streams on purpose: HIP multiplexes streams onto 4 hardware queues, and two streams that share a queue
 	// serialise (measured: the WHB chain stopped overlapping the TFA chains with a fifth stream in the process).
 	hipStream_t fs = nullptr;                     // front-end stream (+ the drain's device-to-host copies)
@@ -183,6 +188,7 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipFree(c->d_dec[k]);
 		(void)hipFree(c->d_mask[k]);
 		(void)hipFree(c->d_fmdev[k]);
+		(void)hipFree(c->d_prevdec[k]);
 		if (c->ev_in[k])
 			(void)hipEventDestroy(c->ev_in[k]);
 		if (c->ev_front[k])
@@ -343,8 +349,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 				rc = TFREC_AMD_E_HIP;
 		}
 	}
-	for (int k = 0; k < 2; k++)
+	for (int k = 0; k < 2; k++) {
 		ALLOC(c->d_fmdev[k], n * m_max * sizeof(int16_t) + 256);  // + slack: K3 reads whole dwords past an odd tail
+		ALLOC(c->d_prevdec[k], n * sizeof(uint32_t));
+	}
+	for (int a = 0; a < c->launch.n_active; a++)
+		c->need_fmdev = c->need_fmdev || c->launch.params[a].kind == 1;
 	if (!(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
 		// window-parallel pipeline buffers (chains2.hip)
 		const size_t chains = (size_t)c->launch.n_active * n;
@@ -524,11 +534,13 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	}
 	HIPCHK(launch_frontend(fs, fin, fstride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
 			       c->d_tail[c->tail_sel ^ 1], c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride,
-			       c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps,
-			       c->in10x));
+			       c->d_prevdec[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps, c->in10x));
 	if (c->d_fsk)  // auto threshold: per-block thresholds rewrite the trigger mask (fm_demod.cpp:58-73)
 		HIPCHK(launch_threshold(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams,
 					n_blocks, c->d_fsk, c->wmax));
+	if (c->need_fmdev)  // FM discriminator of the samples near trigger windows (after the mask is final)
+		HIPCHK(launch_fmdev(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_prevdec[set],
+				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][1], fs));
 	HIPCHK(hipEventRecord(c->ev_front[set], fs));

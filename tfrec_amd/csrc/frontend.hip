@@ -53,8 +53,7 @@ template <bool IN16>
 __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const uint8_t *__restrict__ iq, size_t stride, int m_total, const uint8_t *__restrict__ tail_in,
 	uint8_t *__restrict__ tail_out, uint32_t *__restrict__ dec, size_t dec_stride,
-	unsigned long long *__restrict__ mask, size_t mask_stride, int16_t *__restrict__ fmdev, size_t fmdev_stride,
-	EventBuf *__restrict__ eb, int thresh, FrontTaps taps)
+	unsigned long long *__restrict__ mask, size_t mask_stride, uint32_t *__restrict__ prevdec, int thresh, FrontTaps taps)
 {
 	constexpr int kB = IN16 ? 2 : 1;             // bytes per rail sample
 	constexpr int kTail = kTailBytes * kB;      // history bytes (56 complex samples)
@@ -62,7 +61,6 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
 	__shared__ __attribute__((aligned(16))) int32_t y1i[kY1Count];
 	__shared__ __attribute__((aligned(16))) int32_t y1q[kY1Count];
-	__shared__ uint32_t lastw[kFrontThreads];
 
 	const int s = blockIdx.y;
 	const int tile = blockIdx.x;
@@ -169,38 +167,60 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + lane] = w;
 	}
 
-	// ---- FM discriminator of every decimated sample against its predecessor (fm_dev, dsp_stuff.cpp:284-292):
-	// the fp64 atan2 is a pure map, so it runs here in parallel instead of inside the serial demodulator
-	// chains; TFA_2, TFA_3 and TX22 (tfa2.cpp:361) all consume this one array.
-	lastw[tid] = outw[3];
-	int pI, pQ;
-	if (tid == 0) {
-		// previous decimated sample y2[m0-1] (for m0 == 0 it comes out of the carried raw history,
-		// i.e. the last decimated sample of the previous submit; zero history at stream start)
+	// ---- the decimated sample BEFORE this submit's first one (it comes out of the carried raw history; zero history
+	// at stream start): the FM discriminator pass needs it for sample 0
+	if (tile == 0 && tid == 0) {
 		int si = 0, sq = 0;
 #pragma unroll
 		for (int n = 0; n < 20; n++) {
 			si += mulhi24(taps.s2[n], y1i[2 + n]);
 			sq += mulhi24(taps.s2[n], y1q[2 + n]);
 		}
-		pI = (int)(int16_t)si;
-		pQ = (int)(int16_t)sq;
+		prevdec[s] = ((uint32_t)(int16_t)si & 0xffffu) | ((uint32_t)(int16_t)sq << 16);
 	}
-	__syncthreads();
-	if (tid != 0) {
-		const uint32_t pw = lastw[tid - 1];
-		pI = (int)(int16_t)(pw & 0xffff);
-		pQ = (int)pw >> 16;
+}
+
+// ---- FM discriminator (fm_dev, dsp_stuff.cpp:284-292) of every decimated sample against its predecessor.  The fp64
+// atan2 is a pure map, so it runs here in parallel instead of inside the serial demodulator chains; TFA_2, TFA_3 and
+// TX22 (tfa2.cpp:361) all consume this one array.  Only samples inside a trigger window are ever read: a tile of
+// 1024 samples is computed iff a trigger lies in it or within `wmax` samples before it (wmax = the longest window of
+// the registered demodulators; the first tile always, a window may be open from the previous submit) -- about half
+// of the tiles in the benchmark workload.  Same 256 x 4 lane layout as the front end.
+__global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+							      const unsigned long long *__restrict__ mask, size_t mask_stride,
+							      const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
+							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax)
+{
+	__shared__ int any;
+	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+	const int m0 = tile * kTileDec;
+	const uint32_t *drow = dec + (size_t)s * dec_stride;
+	if (tile > 0 && wmax < kTileDec) {
+		if (tid == 0)
+			any = 0;
+		__syncthreads();
+		const int w0 = (m0 - wmax) >> 6, w1 = (m0 + kTileDec - 1) >> 6;  // m0 >= 1024 > wmax
+		const int w = w0 + tid;
+		if (w <= w1 && mask[(size_t)s * mask_stride + w] != 0ull)
+			any = 1;
+		__syncthreads();
+		if (!any)
+			return;
 	}
+	const uint4 v = *reinterpret_cast<const uint4 *>(drow + m0 + 4 * tid);
+	const uint32_t pw = (m0 + 4 * tid) > 0 ? drow[m0 + 4 * tid - 1] : prevdec[s];
+	const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+	int pI = (int)(int16_t)(pw & 0xffff), pQ = (int)pw >> 16;
 	int dv[4];
 	unsigned n_unc = 0;
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
+		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
 		bool unc;
-		dv[o] = fm_dev(oI[o], oQ[o], pI, pQ, &unc);
+		dv[o] = fm_dev(I, Q, pI, pQ, &unc);
 		n_unc += unc ? 1u : 0u;
-		pI = oI[o];
-		pQ = oQ[o];
+		pI = I;
+		pQ = Q;
 	}
 	if (n_unc)
 		atomicAdd(&eb->uncertain, (unsigned long long)n_unc);
@@ -288,17 +308,29 @@ hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int 
 
 hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			   const uint8_t *tail_in, uint8_t *tail_out, uint32_t *dec, size_t dec_stride,
-			   unsigned long long *mask, size_t mask_stride, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			   int thresh, const FrontTaps &taps, bool in16)
+			   unsigned long long *mask, size_t mask_stride, uint32_t *prevdec, int thresh, const FrontTaps &taps,
+			   bool in16)
 {
 	const int m_total = n_blocks * kBlockDec;
 	dim3 grid(m_total / kTileDec, n_streams);
 	if (in16)
 		hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out,
-				   dec, dec_stride, mask, mask_stride, fmdev, fmdev_stride, eb, thresh, taps);
+				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
 	else
 		hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out,
-				   dec, dec_stride, mask, mask_stride, fmdev, fmdev_stride, eb, thresh, taps);
+				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
+	return hipGetLastError();
+}
+
+// after the front end (and the auto-threshold pass, which rewrites the mask)
+hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
+			int n_streams, int n_blocks, int wmax)
+{
+	const int m_total = n_blocks * kBlockDec;
+	dim3 grid(m_total / kTileDec, n_streams);
+	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFrontThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
+			   fmdev_stride, eb, wmax);
 	return hipGetLastError();
 }
 
