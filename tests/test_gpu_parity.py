@@ -274,3 +274,9 @@ def test_full_size_pipeline_equals_serial_chains_and_replicas():
         assert rep.tobytes() == first.tobytes()
     for s in (0, 17, 47):
         check_stream(a, s, oracle_events(base[s], 0x2F, 500))
+
+
+def test_randomised_campaign():
+    """Random masks / thresholds (incl. auto) / filters / noise / submit splits / submits in flight (tests/stress_gpu.py)."""
+    import stress_gpu
+    assert stress_gpu.campaign(3, 8, verbose=False) == 0
