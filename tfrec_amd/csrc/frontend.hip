@@ -97,28 +97,31 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		int di[14], dq[14];
 		if (IN16) {
 #pragma unroll
-			for (int i = 0; i < 14; i++) {
-				di[i] = (int)(int16_t)(rp[i] & 0xffff);
-				dq[i] = (int)rp[i] >> 16;
+			for (int i = 0; i < 14; i++) {  // x << 8
+				di[i] = (int)(int16_t)(rp[i] & 0xffff) << 8;
+				dq[i] = ((int)rp[i] >> 16) << 8;
 			}
 		} else {
 #pragma unroll
 			for (int i = 0; i < 7; i++) {
-				const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
-				di[2 * i] = (int)(int8_t)(w & 0xff);
-				dq[2 * i] = (int)(int8_t)((w >> 8) & 0xff);
-				di[2 * i + 1] = (int)(int8_t)((w >> 16) & 0xff);
-				dq[2 * i + 1] = (int)w >> 24;
+				const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement (u8 - 128); kept as d << 15
+				di[2 * i] = (int)(w << 24) >> 9;
+				dq[2 * i] = (int)((w << 16) & 0xff000000u) >> 9;
+				di[2 * i + 1] = (int)((w << 8) & 0xff000000u) >> 9;
+				dq[2 * i + 1] = (int)(w & 0xff000000u) >> 9;
 			}
 		}
 		int oi[4], oq[4];
 #pragma unroll
 		for (int o = 0; o < 4; o++) {
+			// (d*h) >> 10 for d = u8-128, (x*h) >> 16 for int16 x: both as the high word of a 24x24-bit product of
+			// pre-shifted operands (d<<15 and h<<7: 23 and 21 bits; x<<8 and h<<8: 24 and 22 bits) -- one full-rate
+			// multiply per tap instead of multiply + shift
 			int si = 0, sq = 0;
 #pragma unroll
 			for (int n = 0; n < 8; n++) {
-				si += (di[2 * o + n] * kS1[n]) >> (IN16 ? 16 : 10);
-				sq += (dq[2 * o + n] * kS1[n]) >> (IN16 ? 16 : 10);
+				si += mulhi24(kS1[n] << (IN16 ? 8 : 7), di[2 * o + n]);
+				sq += mulhi24(kS1[n] << (IN16 ? 8 : 7), dq[2 * o + n]);
 			}
 			oi[o] = (int)(int16_t)si << 8;
 			oq[o] = (int)(int16_t)sq << 8;
