@@ -277,18 +277,18 @@ __global__ __launch_bounds__(256) void decim10_kernel(const uint8_t *__restrict_
 	int acc_i[4] = { 0, 0, 0, 0 }, acc_q[4] = { 0, 0, 0, 0 };
 #pragma unroll
 	for (int w = 0; w < 45; w++) {  // one dword = two complex samples
-		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
-		const int xi[2] = { (int)(int8_t)(v & 0xff), (int)(int8_t)((v >> 16) & 0xff) };
-		const int xq[2] = { (int)(int8_t)((v >> 8) & 0xff), (int)v >> 24 };
+		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128), kept as d << 15
+		const int xi[2] = { (int)(v << 24) >> 9, (int)((v << 8) & 0xff000000u) >> 9 };
+		const int xq[2] = { (int)((v << 16) & 0xff000000u) >> 9, (int)(v & 0xff000000u) >> 9 };
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
 			const int c = 2 * w + h;  // sample index relative to 40*tid + 6
 #pragma unroll
 			for (int o = 0; o < 4; o++) {
 				const int n = c - 10 * o;
-				if (n >= 0 && n < 60) {
-					acc_i[o] += (xi[h] * kTaps10[n]) >> 10;
-					acc_q[o] += (xq[h] * kTaps10[n]) >> 10;
+				if (n >= 0 && n < 60) {  // (d*h) >> 10 as the high word of (h << 7) * (d << 15), cf. stage 1
+					acc_i[o] += mulhi24(kTaps10[n] << 7, xi[h]);
+					acc_q[o] += mulhi24(kTaps10[n] << 7, xq[h]);
 				}
 			}
 		}
