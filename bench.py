@@ -82,8 +82,8 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=48, help="65536-byte blocks per stream per step")
     ap.add_argument("--types", type=lambda x: int(x, 16), default=0x2F)
