@@ -108,10 +108,16 @@ const char *tfrec_amd_strerror(int code);
 /* text of the last HIP error seen by this thread ("" if none) */
 const char *tfrec_amd_last_error(void);
 
+/* Replaces, for cfg->n_streams receivers at once: `downconvert dc(2)` (engine.cpp:59), `fsk_demod fsk(&demods, thresh,
+ * dbg)` (main.cpp:225) and the `new tfa1_demod / tfa2_demod / whb_demod` registrations of main.cpp:173-218
+ * (types_mask = -T, thresh = -t, filter_type = -W). */
 int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out);
 int tfrec_amd_destroy(tfrec_amd_ctx *ctx);
 
-/* Process n_blocks 65536-byte blocks of every stream.  Stream s starts at d_iq + s*stream_stride_bytes
+/* Replaces n_blocks iterations of the block loop engine.cpp:67-86 for every stream: the u8 -> s16 conversion (:77-78),
+ * downconvert::process_iq (:85, dsp_stuff.cpp:243-264) and fsk_demod::process (:86, fm_demod.cpp:34-74) with every
+ * demodulator::start / ::demod and decoder::store_bit it drives (tfa1.cpp:120-190, tfa2.cpp:281-442, whb.cpp:566-707).
+ * Process n_blocks 65536-byte blocks of every stream.  Stream s starts at d_iq + s*stream_stride_bytes
  * (device memory, u8 interleaved I,Q as the reference's -S dump files, sdr.cpp:233-234).  Asynchronous:
  * the work is ordered after what is already queued on hip_stream (a hipStream_t, NULL = default stream) -- the
  * producer of d_iq -- and runs on the context's own streams; d_iq must stay valid until the submit has been
@@ -131,7 +137,9 @@ void tfrec_amd_host_free(void *p);
 /* Wait for submitted work. */
 int tfrec_amd_sync(tfrec_amd_ctx *ctx);
 
-/* Wait for the OLDEST submit that has not been drained yet, then copy its events to out[0..cap), ordered by
+/* Replaces the calls `dec->flush(rssi, offset)` inside tfa1_demod::demod (tfa1.cpp:180), tfa2_demod::demod
+ * (tfa2.cpp:434) and whb_demod::demod (whb.cpp:696): one tfrec_amd_event per call site and window.
+ * Wait for the OLDEST submit that has not been drained yet, then copy its events to out[0..cap), ordered by
  * (stream, slot, seq).  *n_out = number written (0 if nothing was submitted).  Returns TFREC_AMD_E_OVERFLOW if the
  * device buffer or cap was too small (the events that fit are still returned).
  * Submits and drains form a FIFO of depth two: a caller may queue submit k+1 before draining submit k, so that the
@@ -161,10 +169,12 @@ typedef struct {
 				        speculative trajectory (normal for a chain's short last segment) */
 	uint64_t biquad_serial;      /* segments the chain walk had to repair serially */
 	uint64_t tfa2_resliced;      /* tfa2 windows sliced again because the last_bit_idx assumption did not hold */
-	uint64_t reserved[4];
+	uint64_t tfa1_recomputed;    /* 64-sample steps of long TFA_1 windows whose pre-computed peak detector piece did not
+				        start from the true value and were recomputed */
+	uint64_t reserved[3];
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
-/* Current trigger threshold of one stream (auto mode moves it; fixed mode returns cfg.thresh). */
+/* Current trigger threshold of one stream (auto mode, fm_demod.cpp:58-73, moves it; fixed mode returns cfg.thresh). */
 int tfrec_amd_read_thresh(tfrec_amd_ctx *ctx, int stream, int *thresh);
 
 #ifdef __cplusplus

@@ -54,7 +54,7 @@ class Timings(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("biquad_segments", C.c_uint64), ("biquad_unconverged", C.c_uint64), ("biquad_serial", C.c_uint64),
-                ("tfa2_resliced", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 EVENT_DTYPE = np.dtype(
@@ -241,9 +241,7 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        out = {n: int(getattr(st, n)) for n, _ in Stats._fields_[:4]}
-        out["reserved"] = [int(x) for x in st.reserved]
-        return out
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:5]}
 
 
 def event_tuples(events: np.ndarray, stream: int | None = None):
