@@ -34,6 +34,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SAMPLES_PER_BLOCK = 32768
 
 
+def usable_cores() -> int:
+    """Host threads this process may really use: affinity mask, capped by the cgroup CPU quota of the container."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float):
     """Time the reference CPU path, 1 thread, on a bounded sample of the same workload.
 
@@ -76,6 +96,18 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
                            port_value=round(port, 3))
             except Exception as e:  # keep the port number
                 res["reference_error"] = str(e)[:200]
+    # (ii) of SURVEY 8(d): one stream per thread over all host cores (OpenMP inside the C restatement)
+    try:
+        ncpu = usable_cores()
+        a_ = np.ascontiguousarray(iq_sample)
+        n_jobs = max(64, 8 * ncpu)
+        dt = O.lib().orc_time_many(types, thresh, 0, a_.ctypes.data, a_.strides[0], a_.shape[1], n_streams, n_jobs, ncpu)
+        res["all_cores"] = dict(value=round(n_jobs * samples_per_stream / dt / 1e6, 1), unit="MSamples/s", cores=ncpu,
+                                kind="port", sample="%d streams x %d blocks, one receiver per stream, %d threads (of %d "
+                                "logical CPUs; affinity / cgroup quota of this container)" % (
+                                    n_jobs, samples_per_stream // SAMPLES_PER_BLOCK, ncpu, os.cpu_count() or 1))
+    except Exception as e:
+        res["all_cores_error"] = str(e)[:200]
     return res
 
 

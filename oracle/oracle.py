@@ -73,6 +73,8 @@ def lib():
         L.orc_process_s16.restype = C.c_long
         L.orc_process_s16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_decim10.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_time_many.restype = C.c_double
+        L.orc_time_many.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]
         L.orc_hex.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_num_events.restype = C.c_size_t
         L.orc_num_events.argtypes = [C.c_void_p]

@@ -183,7 +183,7 @@ int orc_fm_dev_nrzs(int ar, int aj, int br, int bj)
 	return cr;
 }
 
-static uint64_t g_uncertain; /* diagnostics only, see orc_atan_uncertain() */
+static _Thread_local uint64_t g_uncertain; /* diagnostics only (per thread), see orc_atan_uncertain() */
 
 int orc_fm_dev(int ar, int aj, int br, int bj)
 {
@@ -1153,6 +1153,25 @@ void orc_decim10(const uint8_t *iq, size_t n_in, int16_t *out)
 		out[2 * m] = (int16_t)si;
 		out[2 * m + 1] = (int16_t)sq;
 	}
+}
+
+/* CPU-baseline helper (bench.py): n_streams independent quiet receivers, one stream each, spread over `threads`
+ * OpenMP threads; returns the wall time in seconds.  One receiver per stream is what N copies of the reference
+ * program would do on N cores. */
+#include <omp.h>
+double orc_time_many(int types_mask, int thresh, int wide, const uint8_t *iq, size_t stride, size_t nbytes, int n_streams,
+		     int n_jobs, int threads)
+{
+	build_tabs();
+	const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+	for (int k = 0; k < n_jobs; k++) {
+		orc_t *o = orc_create(types_mask, thresh, wide);
+		orc_set_quiet(o, 1);
+		orc_process(o, iq + (size_t)(k % n_streams) * stride, nbytes);
+		orc_destroy(o);
+	}
+	return omp_get_wtime() - t0;
 }
 
 /* main.cpp:45-49 with decoder::store_bytes (decoder.cpp:35-40) */

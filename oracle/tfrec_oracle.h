@@ -55,6 +55,10 @@ long orc_process_s16(orc_t *o, const int16_t *x, size_t n_values);
 extern const int16_t orc_taps10[60];
 void orc_decim10(const uint8_t *iq, size_t n_in_complex, int16_t *out);
 
+/* CPU-baseline helper: n_jobs quiet receivers (job k reads stream k % n_streams) over `threads` OpenMP threads; seconds */
+double orc_time_many(int types_mask, int thresh, int wide, const uint8_t *iq, size_t stride, size_t nbytes, int n_streams,
+		     int n_jobs, int threads);
+
 /* -X replay (main.cpp:24-53): store_bytes + flush(0) on every registered decoder. */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len);
 
