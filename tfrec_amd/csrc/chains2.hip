@@ -33,11 +33,12 @@
 
 namespace tfrec {
 
-static int env_int(const char *name, int dflt)
+// experiment knobs: integer from the environment, `dflt` when unset or outside [lo, hi]
+static int env_int(const char *name, int dflt, int lo = 0, int hi = 1 << 30)
 {
 	const char *v = getenv(name);
 	const int x = v ? atoi(v) : dflt;
-	return x >= 1 && x <= 64 ? x : dflt;
+	return x >= lo && x <= hi ? x : dflt;
 }
 
 constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
@@ -2271,16 +2272,16 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		return e;
 	// Lanes per wave for the serial kernels (tunable for experiments: TFREC_AMD_LANES_*).  Measured on MI355X:
 	// fewer lanes per wave (less lock-step divergence, more waves) is NOT faster -- full waves win.
-	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64);
+	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64, 1, 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64, 1, 64);
 	dim3 block(64);
 	dim3 grid((n_streams + lanes_chain - 1) / lanes_chain, L.n_active);
 	const int win_blocks = std::min(16384, (int)(((size_t)n_streams * n_blocks * 2 + lanes_win - 1) / lanes_win));
 	// biquad segments: at most (M/32 + windows)/kSegSlots + 1 per chain
 	const int seg_blocks = std::min(16384, (int)(((size_t)L.n_active * n_streams * ((size_t)n_blocks * (kBlockDec / 32) / kSegSlots + 4) +
 						       lanes_win - 1) / lanes_win));
-	static const int long_window = env_int("TFREC_AMD_COOP_MIN", kLongWindow);
+	static const int long_window = env_int("TFREC_AMD_COOP_MIN", kLongWindow, 356);
 	// long windows: at most M / long_window per chain
-	const int coop_blocks = std::min(env_int("TFREC_AMD_COOP_BLOCKS", 8192), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
+	const int coop_blocks = std::min(env_int("TFREC_AMD_COOP_BLOCKS", 32768, 1, 1 << 20), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
 								((size_t)n_blocks * kBlockDec / (size_t)std::max(long_window, 356) + 1), 1u << 30)));
 	const int dec_blocks = std::min(16384, std::max(1, win_blocks));
 	(void)slicer_waves;
