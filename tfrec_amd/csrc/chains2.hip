@@ -482,54 +482,71 @@ __device__ __forceinline__ bool same_bits(double a, double b) { return __double_
 // REPAIR = true: stores outputs and stops after the first slot (>= min_slots slots, >= 2 samples in) whose end
 // state equals the stored checkpoint bit for bit (the two last inputs are then shared too: from there on the
 // stored trajectory is the continuation of this run).  Returns the slots processed.
+// position in a chain's sequence of in-window slots
+struct SegCursor {
+	int j, i;
+	SegWin w;
+};
+__device__ __forceinline__ void seg_advance(SegCursor &p, const WinTables &T, int c, int M, int count)
+{
+	if (++p.i >= p.w.nch) {
+		p.i = 0;
+		p.j = p.j + 1 < count ? p.j + 1 : p.j;  // (never used past the chain's last slot)
+		p.w = seg_win(T, c, p.j, M);
+	}
+}
+
 template <bool WHB, bool REPAIR>
 __device__ __forceinline__ int seg_run(Biquad &f, const BiquadCoef &cf, const void *in, void *out, uint32_t prev0,
 				       const WinTables &T, int c, int M, int count, int j, int i, int nslots, int min_slots,
 				       bool &converged)
 {
-	SegWin cw = seg_win(T, c, j, M);
-	SegWin nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
 	double2 *ckrow = T.ckpt + (size_t)c * T.slots;
 	int done = 0, nsamples = 0;
 	converged = false;
-	K3Chunk<WHB> A, B;
-	double2 ckA = make_double2(0, 0), ckB = make_double2(0, 0);
-	k3_load<WHB>(A, in, cw.og + kChunk * i, prev0);
-	if (REPAIR)
-		ckA = ckrow[cw.slot0 + i];
-	// one slot: `cur` is loaded, the slot after it goes to `nxt` while `cur` is filtered; false = stop
-	auto one = [&](const K3Chunk<WHB> &cur, const double2 &ckcur, K3Chunk<WHB> &nxt, double2 &cknxt) -> bool {
-		const bool hop = i + 1 >= cw.nch;
-		const bool more = done + 1 < nslots;
-		const int og2 = hop ? nw.og : cw.og, i2 = hop ? 0 : i + 1, slot2 = (hop ? nw.slot0 : cw.slot0) + i2;
-		if (more) {
-			k3_load<WHB>(nxt, in, og2 + kChunk * i2, prev0);
+	// three slot buffers in rotation: slot k is filtered while slots k+1 and k+2 are in flight (a lane streams its
+	// own row: what bounds these passes is the latency of the scattered 16-byte loads, not their bandwidth)
+	K3Chunk<WHB> A, B, C;
+	double2 ckA = make_double2(0, 0), ckB = ckA, ckC = ckA;
+	SegCursor pp, pl;  // processing / loading position
+	pp.j = j;
+	pp.i = i;
+	pp.w = seg_win(T, c, j, M);
+	pl = pp;
+	int loaded = 0;
+	auto fetch = [&](K3Chunk<WHB> &buf, double2 &ck) {
+		if (loaded < nslots) {
+			k3_load<WHB>(buf, in, pl.w.og + kChunk * pl.i, prev0);
 			if (REPAIR)
-				cknxt = ckrow[slot2];
+				ck = ckrow[pl.w.slot0 + pl.i];
+			loaded++;
+			if (loaded < nslots)
+				seg_advance(pl, T, c, M, count);
 		}
+	};
+	fetch(A, ckA);
+	fetch(B, ckB);
+	// one slot: `cur` is loaded; the buffer freed by the previous slot receives slot k+2; false = stop
+	auto one = [&](const K3Chunk<WHB> &cur, const double2 &ckcur, K3Chunk<WHB> &spare, double2 &ckspare) -> bool {
+		fetch(spare, ckspare);
 		uint32_t ow[WHB ? 32 : 16];
-		const int nv = cw.n - kChunk * i < kChunk ? cw.n - kChunk * i : kChunk;
+		const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
 		k3_filter<WHB>(f, cf, cur, nv, ow);
-		k3_store<WHB>(out, cw.slot0 + i, ow);
+		k3_store<WHB>(out, pp.w.slot0 + pp.i, ow);
 		nsamples += nv;
 		done++;
 		if (!REPAIR) {
-			ckrow[cw.slot0 + i] = make_double2(f.yn, f.yn1);
+			ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
 		} else if (same_bits(f.yn, ckcur.x) && same_bits(f.yn1, ckcur.y) && nsamples >= 2 && done >= min_slots) {
 			converged = true;
 			return false;
 		}
-		if (!more)
+		if (done >= nslots)
 			return false;
-		if (hop) {
-			j++;
-			cw = nw;
-			nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
-		}
-		i = i2;
+		seg_advance(pp, T, c, M, count);
 		return true;
 	};
-	while (one(A, ckA, B, ckB) && one(B, ckB, A, ckA)) {
+	while (one(A, ckA, C, ckC) && one(B, ckB, A, ckA) && one(C, ckC, B, ckB)) {
 	}
 	return done;
 }
