@@ -1618,13 +1618,30 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	if (count > 0) {
 		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
 		int j = 0, i = 0, nent = 0;
-		Dev3 cur = load_dev(cw.slot0, 0);
+		// the stage-1 outputs of step k + `ahead`, looking across the window boundaries known here (cw, nw, nnw); past
+		// the chain's end any valid slot is read and never used
+		auto load_ahead = [&](int ahead) -> Dev3 {
+			int ii = i + ahead;
+			if (ii < cw.nch)
+				return load_dev(cw.slot0, ii);
+			ii -= cw.nch;
+			if (j + 1 < count) {
+				if (ii < nw.nch)
+					return load_dev(nw.slot0, ii);
+				ii -= nw.nch;
+				if (j + 2 < count && ii < nnw.nch)
+					return load_dev(nnw.slot0, ii);
+			}
+			return load_dev(cw.slot0, 0);
+		};
+		// Two steps stay in flight: beside the other chains' kernels a load takes longer than a step's arithmetic, and
+		// with one step in flight this kernel ran at the speed of the memory system (10 instead of 7 ms)
+		Dev3 cur = load_ahead(0), nxt = load_ahead(1);
 		int pd1 = 0, pd2 = 0;  // stage-1 outputs of the two samples before this step (same window)
 		while (j < count) {
-			// ---- (1) this step's inputs; the next step's are already in flight
+			// ---- (1) this step's inputs; the next two steps' are in flight
 			const int nv = cw.n - kStep * i < kStep ? cw.n - kStep * i : kStep;
-			const bool wnext = i + 1 >= cw.nch;
-			const Dev3 nxt = load_dev(wnext ? (j + 1 < count ? nw.slot0 : cw.slot0) : cw.slot0, wnext ? 0 : i + 1);
+			const Dev3 nxt2 = load_ahead(2);
 			const int og = cw.og, n = cw.n;
 			uint32_t iqw = 0;  // the lane's decimated sample (rssi: only while the decoder is locked)
 			if (synced)
@@ -1785,6 +1802,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				nent = 0;
 			}
 			cur = nxt;
+			nxt = nxt2;
 			if (++i >= cw.nch) {
 				j++;
 				i = 0;
@@ -2344,8 +2362,13 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		mark(12, ws);
 		for (int a = 0; a < L.n_active; a++)
 			if (L.params[a].kind == 2) {
-				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, 0, ws, dec, dec_stride, dev32,
-						   n_streams, n_blocks, L, a, T);
+				// 22 KB of dynamic LDS nobody uses: at most 7 of this kernel's one-wave workgroups fit on a CU.  It is
+				// launched while the other chains' kernels occupy the chip; without the cap the dispatcher piles its
+				// waves onto the few CUs that happen to have room, where they share SIMDs with each other for their
+				// whole life (measured: 10.4 -> 8.5 ms; above 24 KB the workgroups start to wait for LDS: 12 ms)
+				static const int whb_lds = env_int("TFREC_AMD_WHB_LDS", 22000, 0, 64 << 10);
+				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, ws, dec, dec_stride, dev32, n_streams,
+						   n_blocks, L, a, T);
 				mark(13, ws);
 				hipLaunchKernelGGL(whb_decode_kernel, dim3(std::max(1, dec_blocks / 4)), block, 0, ws, n_streams, L, a, T);
 				mark(14, ws);
