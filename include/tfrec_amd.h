@@ -92,7 +92,7 @@ typedef struct tfrec_amd_ctx tfrec_amd_ctx;
 
 /* kernel timings of the last submit (TFREC_AMD_F_TIMING), milliseconds */
 typedef struct {
-	float frontend_ms; /* u8->s16 + 2-stage decimating FIR + trigger mask + FM discriminator kernel */
+	float frontend_ms; /* (10:1 stage,) u8->s16 + 2-stage decimating FIR + trigger mask (+ auto-threshold pass) */
 	float chains_ms;   /* all demodulator/decoder kernels together (end of front end -> end of last kernel) */
 	float total_ms;    /* first kernel start to last kernel end */
 	/* individual kernels of the window-parallel pipeline (0 when not run).  Window scan, then the TFA_2-family chain: */
@@ -101,6 +101,7 @@ typedef struct {
 	float whb_biquad_ms, whb_demod_ms, whb_decode_ms, whb_commit_ms;
 	/* ... and so does the TFA_1 chain (no biquad stage): short-window slicer, cooperative slicer, decode + commit */
 	float tfa1_slicer_ms, tfa1_coop_slicer_ms, tfa1_decode_commit_ms;
+	float fmdev_ms;    /* FM discriminator pass of the front end (tiles near trigger windows) */
 } tfrec_amd_timings;
 
 const char *tfrec_amd_version(void);

@@ -49,7 +49,7 @@ class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("frontend_ms", "chains_ms", "total_ms", "windows_ms", "spec_biquad_ms",
                                          "repair_biquad_ms", "fix_biquad_ms", "slicer_ms", "coop_slicer_ms", "decode_ms",
                                          "commit_ms", "whb_biquad_ms", "whb_demod_ms", "whb_decode_ms", "whb_commit_ms",
-                                         "tfa1_slicer_ms", "tfa1_coop_slicer_ms", "tfa1_decode_commit_ms")]
+                                         "tfa1_slicer_ms", "tfa1_coop_slicer_ms", "tfa1_decode_commit_ms", "fmdev_ms")]
 
 
 class Stats(C.Structure):

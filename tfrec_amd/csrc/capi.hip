@@ -93,7 +93,7 @@ struct tfrec_amd_ctx {
 	long long sample_base = 0;
 	int last_blocks = 0;
 	hipStream_t last_stream = nullptr;
-	hipEvent_t ev[2][3] = { { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr } };
+	hipEvent_t ev[2][4] = {};  // start, after the front end, end of the submit, after the discriminator pass
 	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	hipEvent_t tev[2][21] = {};
@@ -538,6 +538,8 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	if (c->d_fsk)  // auto threshold: per-block thresholds rewrite the trigger mask (fm_demod.cpp:58-73)
 		HIPCHK(launch_threshold(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams,
 					n_blocks, c->d_fsk, c->wmax));
+	if (timing)
+		HIPCHK(hipEventRecord(c->ev[set][3], fs));
 	if (c->need_fmdev)  // FM discriminator of the samples near trigger windows (after the mask is final)
 		HIPCHK(launch_fmdev(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_prevdec[set],
 				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax));
@@ -760,7 +762,8 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	const int set = c->last_drained >= 0 ? c->last_drained : c->head;
 	hipEvent_t *ev = c->ev[set], *tev = c->tev[set];
 	HIPCHK(hipEventSynchronize(ev[2]));
-	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[1]));
+	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[3]));
+	HIPCHK(hipEventElapsedTime(&out->fmdev_ms, ev[3], ev[1]));
 	HIPCHK(hipEventElapsedTime(&out->chains_ms, ev[1], ev[2]));
 	HIPCHK(hipEventElapsedTime(&out->total_ms, ev[0], ev[2]));
 	out->windows_ms = out->spec_biquad_ms = out->repair_biquad_ms = out->fix_biquad_ms = out->slicer_ms = 0;
