@@ -276,6 +276,25 @@ def test_full_size_pipeline_equals_serial_chains_and_replicas():
         check_stream(a, s, oracle_events(base[s], 0x2F, 500))
 
 
+def test_tfa2_edge_timing_speculation_failure_is_resliced_exactly():
+    """A TFA_2-family window is sliced before its predecessor's last_bit_idx is known (assumed far in the past); when
+    the assumption fails the commit step re-slices it with the exact value.  These two synthetic streams hit that path
+    on their second pass (found by profiles/ubench/find_reslice.py): the re-slice must have happened, and the events
+    must still be the oracle's."""
+    n_blocks = 12
+    iq = np.concatenate([synth.gen_batch(1000, s, 1, n_blocks) for s in (2387, 3079)])
+    with api.Receiver(2, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True) as r:
+        evs = []
+        for _ in range(2):
+            r.submit(iq)
+            evs.append(r.drain())
+        assert r.stats()["tfa2_resliced"] > 0
+        ev = np.concatenate(evs)
+        ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
+    for s in range(2):
+        check_stream(ev, s, oracle_events(np.concatenate([iq[s], iq[s]]), 0x2F, 500))
+
+
 def test_randomised_campaign():
     """Random masks / thresholds (incl. auto) / filters / noise / submit splits / submits in flight (tests/stress_gpu.py)."""
     import stress_gpu

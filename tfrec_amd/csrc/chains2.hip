@@ -1182,7 +1182,7 @@ struct CoopBits {
 
 __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					  size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
-					  const WinTables &T)
+					  const WinTables &T, bool fresh = false, int fresh_lbi = 0)
 {
 	const int lane = threadIdx.x;
 	const int a = c / n_streams, s = c - a * n_streams;
@@ -1194,14 +1194,27 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	const int16_t *ldrow = ld16 + (size_t)c * T.slots * 32 + (size_t)win_slot0(og, j) * 32;  // window-relative
 	// ---- wave-uniform slicer state (tfa2.h:35-42): where the lane-per-window head (slicer_kernel) stopped
+	// (fresh: the whole window from its first sample, with the given last_bit_idx -- commit's exact re-slice)
 	WinResult &rr = T.result[(size_t)c * T.cap + j];
-	const WinResult r0 = rr;
+	WinResult r0 = rr;
+	if (fresh) {  // tfa2.cpp:436-441 as the previous window's timeout left the demodulator
+		r0.resume = 0;
+		r0.nbits = 0;
+		r0.rssi_i = 0;
+		r0.bitcnt = 0;
+		r0.dmin = 32767;
+		r0.dmax = -32767;
+		r0.offset = 0;
+		r0.last_bit = 0;
+		r0.first_cand_g = -1;
+		r0.lbi_out = fresh_lbi;
+	}
 	if (r0.resume < 0)
 		return;  // the head finished the window
 	const int g1 = og + kChunk * r0.resume;  // first sample still to do
 	int rssi_i = r0.rssi_i, bitcnt = r0.bitcnt, dmin = r0.dmin, dmax = r0.dmax, offset = r0.offset;
 	int last_bit = r0.last_bit, first_cand_g = r0.first_cand_g;
-	int cur_block = (g1 - 1) >> 13;
+	int cur_block = fresh ? og >> 13 : (g1 - 1) >> 13;
 	int lbi = r0.lbi_out;  // relative to cur_block (run_window leaves it relative to the block of its last sample)
 	// integer form of "tdiff > spb / 4 && tdiff < 32 * spb" (tdiff is an integer)
 	const int td_lo = (int)floor(spb / 4) + 1;
@@ -2031,7 +2044,7 @@ __global__ __launch_bounds__(64) void whb_commit_kernel(const uint32_t *__restri
 //                      window can be decoded without the windows before it.  What does cross windows: TFA_1's
 //                      shift register (not cleared by flush) -- re-created from the tail of the preceding windows'
 //                      bits -- and the stale bytes of rdata[] beyond this window's byte_cnt, handled in K5b.
-//   K5b commit_kernel  lane per (stream, slot): walks the windows in order: validates/repairs the tfa2
+//   K5b commit_kernel  lane per (stream, slot) for TFA_1, commit_wave_kernel wave per (stream, slot) for the TFA_2 family: walks the windows in order: validates/repairs the tfa2
 //                      last_bit_idx speculation, overlays the windows' rdata bytes in order (rdata persistence),
 //                      emits the flush events and commits ChainState for the next submit.  O(64 bytes) per window.
 __device__ __forceinline__ const uint32_t *win_bits(const WinTables &T, int c, int j, int og)
@@ -2132,7 +2145,9 @@ __global__ __launch_bounds__(64) void decode_kernel(int n_streams, ChainLaunch L
 	}
 }
 
-template <int KIND>
+// WAVE: the whole wave walks ONE chain in lock step (every lane computes the same); only lane 0 reports events and
+// stores state.  That way the rare exact re-slice of a window is the wave-cooperative slicer, not one lane's.
+template <int KIND, bool WAVE>
 __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_blocks, long long sample_base,
 					    const uint32_t *__restrict__ dec, size_t dec_stride,
 					    const int16_t *__restrict__ ld16, const ChainLaunch &L, const WinTables &T,
@@ -2144,7 +2159,8 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 	ChainState &st = L.states[a][s];
 	const int c = a * n_streams + s;
 	const int count = T.count[c];
-	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
+	const bool lead = !WAVE || threadIdx.x == 0;
+	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base, !lead };
 	{  // rdata[0 .. 64) as the previous submit left them (only these are ever looked at: INTEGRATION.md)
 		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
 		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
@@ -2174,9 +2190,17 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 					// (tfa2.cpp:391-409 with a huge tdiff).  The true run does the same iff:
 					const bool same = (index_c > lbi_c + 8) && !(tdiff > p.spb / 4 && tdiff < 32 * p.spb);
 					if (!same) {  // slice and decode this window again, exactly (rare)
-						atomicAdd(&T.stats[3], 1ull);
-						window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
-							       rebase_lbi(lbi, lbi_block, og >> 13), my_lds, 0);
+						if (lead)
+							atomicAdd(&T.stats[3], 1ull);
+						if (WAVE) {
+							coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
+								  rebase_lbi(lbi, lbi_block, og >> 13));
+							__threadfence();  // lane 0's stores (bits, result) before every lane reads them
+							__syncthreads();
+						} else {
+							window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
+								       rebase_lbi(lbi, lbi_block, og >> 13), my_lds, 0);
+						}
 						uint4 keep[4];
 #pragma unroll
 						for (int q = 0; q < 4; q++)
@@ -2218,6 +2242,8 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 		last_r = rr;
 	}
 	// ---- commit the state the next submit starts from
+	if (!lead)
+		return;
 	const bool open_at_end = last_r && !last_r->closed;
 	if (open_at_end) {
 		st.mark_lvl = last_r->mark_lvl;
@@ -2279,11 +2305,26 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 	if (kind != want_kind)
 		return;
 	if (kind == 0)
-		commit_body<0>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
-			       my_rdata);
+		commit_body<0, false>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
+				      my_rdata);
 	else if (kind == 1)
-		commit_body<1>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
-			       my_rdata);
+		commit_body<1, false>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
+				      my_rdata);
+}
+
+// TFA_2 family: one wave per chain (blockIdx.x = stream, blockIdx.y = slot)
+__global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+							 const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
+							 long long sample_base, ChainLaunch L, WinTables T,
+							 tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb,
+							 uint32_t flags)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[256];
+	const int a = blockIdx.y;
+	if (L.params[a].kind != 1)
+		return;
+	commit_body<1, true>(a, blockIdx.x, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags,
+			     nullptr, rdata_lds);
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -2416,8 +2457,13 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		mark(m0 + 2, s_);
 		hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks), block, 0, s_, n_streams, L, T, kind);
 		mark(m0 + 3, s_);
-		hipLaunchKernelGGL(commit_kernel, grid, block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
-				   events, eb, flags, lanes_chain, kind);
+		static const int wave_commit = env_int("TFREC_AMD_WAVE_COMMIT", 1);
+		if (kind == 1 && wave_commit)
+			hipLaunchKernelGGL(commit_wave_kernel, dim3(n_streams, L.n_active), block, 0, s_, dec, dec_stride, ld16,
+					   n_streams, n_blocks, sample_base, L, T, events, eb, flags);
+		else
+			hipLaunchKernelGGL(commit_kernel, grid, block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, sample_base,
+					   L, T, events, eb, flags, lanes_chain, kind);
 		mark(m0 + 4, s_);
 	};
 	if (t1_forked) {

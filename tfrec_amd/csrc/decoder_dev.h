@@ -98,6 +98,7 @@ struct EmitCtx {
 	int slot;
 	int sensor_type;
 	long long sample_base;
+	bool quiet = false;  // compute everything, report nothing (the non-leading lanes of a wave-per-chain kernel)
 };
 
 // one lane's working copy of the decoder (registers) + its rdata in global memory
@@ -177,7 +178,7 @@ template <int KIND>
 __device__ inline void flush(const EmitCtx &e, Dec &d, long long rssi_raw, int offset, int g)
 {
 	const int verdict = flush_verdict<KIND>(d.rdata, d.byte_cnt, e.sensor_type);
-	if ((e.flags & TFREC_AMD_F_ALL_FLUSHES) || verdict != 0) {
+	if (!e.quiet && ((e.flags & TFREC_AMD_F_ALL_FLUSHES) || verdict != 0)) {
 		const uint32_t idx = atomicAdd(&e.eb->count, 1u);
 		if (idx < e.eb->capacity) {
 			tfrec_amd_event *ev = e.events + idx;
