@@ -378,8 +378,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_count = carve(chains * 4), o_cont = carve(chains * 4), o_tnext = carve(chains * 4);
 		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
 		const size_t o_dcd = carve(wins * sizeof(WinDecode)), o_wst = carve(whb ? n * (size_t)T.cap * sizeof(WhbStart) : 0);
-		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve(kNQueues * wins * sizeof(uint2));
-		const size_t o_queue = carve(kNQueues * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(64);
+		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve((kNQueues * wins + chains) * sizeof(uint2));
+		const size_t o_queue = carve((kNQueues + 1) * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(64);
 		T.segcap = (int32_t)((m_max / 32 + (size_t)T.cap) / kSegSlots + 2);
 		const size_t segs = chains * (size_t)T.segcap;
 		const size_t o_ckpt = carve(chains * (size_t)T.slots * sizeof(double2));
@@ -413,7 +413,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.segfix2 = (int32_t *)(b + o_sfix2);
 			T.cand = (uint32_t *)(b + o_cand);
 			T.mark = (MarkPiece *)(b + o_mark);
-			if (hipMemset(T.queue, 0, kNQueues * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
+			if (hipMemset(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
 			    hipMemset(T.stats, 0, 64) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}

@@ -2152,7 +2152,7 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 					    const uint32_t *__restrict__ dec, size_t dec_stride,
 					    const int16_t *__restrict__ ld16, const ChainLaunch &L, const WinTables &T,
 					    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
-					    uint4 *__restrict__ my_lds, uint8_t *__restrict__ my_rdata)
+					    uint8_t *__restrict__ my_rdata)
 {
 	const int M = n_blocks * kBlockDec;
 	const ChainParams &p = L.params[a];
@@ -2170,6 +2170,31 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 	}
 	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
 	       my_rdata };
+	if (KIND == 1 && !WAVE) {
+		// First only the edge-timing check of every window (see below).  A chain with a window that fails it is handed
+		// to commit_wave_kernel, where the exact re-slice is the wave-cooperative slicer; nothing of it is committed here.
+		int lbi = st.last_bit_idx, lbi_block = -1;
+		bool ok = true;
+		for (int j = 0; j < count && ok; j++) {
+			const int close = T.close[(size_t)c * T.cap + j];
+			const int last = close < M ? close : M - 1;
+			const WinResult *rr = &T.result[(size_t)c * T.cap + j];
+			if (j > 0 && rr->first_cand_g >= 0) {
+				const int index_c = 2 * (rr->first_cand_g & (kBlockDec - 1));
+				const int lbi_c = rebase_lbi(lbi, lbi_block, rr->first_cand_g >> 13);
+				const int tdiff = index_c - lbi_c;
+				ok = (index_c > lbi_c + 8) && !(tdiff > p.spb / 4 && tdiff < 32 * p.spb);
+			}
+			lbi = (j == 0 || rr->first_cand_g >= 0) ? rr->lbi_out : rebase_lbi(lbi, lbi_block, last >> 13);
+			lbi_block = last >> 13;
+		}
+		if (!ok) {
+			const size_t total = (size_t)L.n_active * n_streams * T.cap;
+			const uint32_t idx = atomicAdd(&T.queue[kDeferQueue].count, 1u);
+			T.items[(size_t)kNQueues * total + idx] = make_uint2((uint32_t)a, (uint32_t)s);
+			return;
+		}
+	}
 	int lbi = st.last_bit_idx;  // true last_bit_idx, relative to lbi_block
 	int lbi_block = -1;
 	const WinResult *last_r = nullptr;
@@ -2189,18 +2214,14 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 					// the speculative run saw: glitch test passed, edge counted, nothing emitted, last_bit kept
 					// (tfa2.cpp:391-409 with a huge tdiff).  The true run does the same iff:
 					const bool same = (index_c > lbi_c + 8) && !(tdiff > p.spb / 4 && tdiff < 32 * p.spb);
-					if (!same) {  // slice and decode this window again, exactly (rare)
+					if (WAVE && !same) {  // slice and decode this window again, exactly (rare; the lane-per-chain
+							      // form never gets here: it deferred the chain above)
 						if (lead)
 							atomicAdd(&T.stats[3], 1ull);
-						if (WAVE) {
-							coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
-								  rebase_lbi(lbi, lbi_block, og >> 13));
-							__threadfence();  // lane 0's stores (bits, result) before every lane reads them
-							__syncthreads();
-						} else {
-							window_task<1>(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
-								       rebase_lbi(lbi, lbi_block, og >> 13), my_lds, 0);
-						}
+						coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
+							  rebase_lbi(lbi, lbi_block, og >> 13));
+						__threadfence();  // lane 0's stores (bits, result) before every lane reads them
+						__syncthreads();
 						uint4 keep[4];
 #pragma unroll
 						for (int q = 0; q < 4; q++)
@@ -2293,9 +2314,7 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 						    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
 						    int lanes, int want_kind)
 {
-	__shared__ uint4 slot_lds[8 * 64];
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
-	uint4 *my_lds = slot_lds + threadIdx.x;
 	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
 	const int a = blockIdx.y;
 	const int s = blockIdx.x * lanes + threadIdx.x;
@@ -2305,14 +2324,12 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 	if (kind != want_kind)
 		return;
 	if (kind == 0)
-		commit_body<0, false>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
-				      my_rdata);
+		commit_body<0, false>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_rdata);
 	else if (kind == 1)
-		commit_body<1, false>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_lds,
-				      my_rdata);
+		commit_body<1, false>(a, s, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags, my_rdata);
 }
 
-// TFA_2 family: one wave per chain (blockIdx.x = stream, blockIdx.y = slot)
+// TFA_2 family, the chains commit_kernel deferred: one wave per chain
 __global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ ld16, int n_streams, int n_blocks,
 							 long long sample_base, ChainLaunch L, WinTables T,
@@ -2320,11 +2337,14 @@ __global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restr
 							 uint32_t flags)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[256];
-	const int a = blockIdx.y;
-	if (L.params[a].kind != 1)
-		return;
-	commit_body<1, true>(a, blockIdx.x, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb, flags,
-			     nullptr, rdata_lds);
+	const size_t total = (size_t)L.n_active * n_streams * T.cap;
+	const uint32_t count = T.queue[kDeferQueue].count;
+	for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+		const uint2 it = T.items[(size_t)kNQueues * total + idx];
+		commit_body<1, true>((int)it.x, (int)it.y, n_streams, n_blocks, sample_base, dec, dec_stride, ld16, L, T, events, eb,
+				     flags, rdata_lds);
+		__syncthreads();
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ launch
@@ -2343,7 +2363,7 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	};
 	if (L.n_active == 0)
 		return hipSuccess;
-	hipError_t e = hipMemsetAsync(T.queue, 0, kNQueues * sizeof(WorkQueue), st);
+	hipError_t e = hipMemsetAsync(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue), st);
 	if (e != hipSuccess)
 		return e;
 	// Lanes per wave for the serial kernels (tunable for experiments: TFREC_AMD_LANES_*).  Measured on MI355X:
@@ -2457,13 +2477,11 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 		mark(m0 + 2, s_);
 		hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks), block, 0, s_, n_streams, L, T, kind);
 		mark(m0 + 3, s_);
-		static const int wave_commit = env_int("TFREC_AMD_WAVE_COMMIT", 1);
-		if (kind == 1 && wave_commit)
-			hipLaunchKernelGGL(commit_wave_kernel, dim3(n_streams, L.n_active), block, 0, s_, dec, dec_stride, ld16,
-					   n_streams, n_blocks, sample_base, L, T, events, eb, flags);
-		else
-			hipLaunchKernelGGL(commit_kernel, grid, block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, sample_base,
-					   L, T, events, eb, flags, lanes_chain, kind);
+		hipLaunchKernelGGL(commit_kernel, grid, block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, sample_base, L, T,
+				   events, eb, flags, lanes_chain, kind);
+		if (kind == 1)  // the few chains (normally none) with a window to slice again
+			hipLaunchKernelGGL(commit_wave_kernel, dim3(256), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks,
+					   sample_base, L, T, events, eb, flags);
 		mark(m0 + 4, s_);
 	};
 	if (t1_forked) {

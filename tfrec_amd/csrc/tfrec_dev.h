@@ -182,6 +182,9 @@ struct WinTables {
 };
 
 constexpr int kNQueues = 8;
+// one more counter after the work queues, with a (stream, slot) list behind the queues' items: the TFA_2-family
+// chains whose commit found a window sliced under a wrong last_bit_idx assumption (commit_wave_kernel takes them)
+constexpr int kDeferQueue = kNQueues;
 constexpr int kSegSlots = 128;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
 constexpr int kSegConverged = 0x40000000, kSegRan = 0x20000000;
 constexpr int kLongWindow = 2048;  // samples; longer windows go to the wave-cooperative slicers (default)
