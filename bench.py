@@ -24,7 +24,10 @@ import sys
 import tempfile
 import time
 
-import numpy as np
+# before anything initialises HIP: six streams of the deep pipeline layout need more than the default 4 hardware queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -123,6 +126,7 @@ def main():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic streams to generate per GPU (0 = auto)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--parity-streams", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=3, help="batches kept in the submit/drain FIFO (1..3)")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
                          "(secondary measurement; the default line stays config 2)")
@@ -192,16 +196,18 @@ def main():
             print("PARITY FAILURE on rank %d" % rank, file=sys.stderr)
             sys.exit(3)
 
-    # Submits and drains form a FIFO of depth two (include/tfrec_amd.h): batch k+1 is queued before batch k's events
-    # are drained, so the GPU never waits for the host's copy + sort of the previous batch.
+    # Submits and drains form a FIFO (include/tfrec_amd.h, TFREC_AMD_FIFO_DEPTH): up to `depth` batches are queued before
+    # the oldest one's events are drained, so the GPU never waits for the host's copy + sort of a batch and the stages
+    # of consecutive batches overlap.  Exactly n_steps batches are submitted and drained inside run().
+    depth = max(1, min(a.depth, api.FIFO_DEPTH))
+
     def run(n_steps, collect):
         n_ev = 0
-        if n_steps < 1:
-            return 0
-        r.submit(d_iq)
+        queued = 0
         for k in range(n_steps):
-            if k + 1 < n_steps:
+            while queued < n_steps and queued - k < depth:
                 r.submit(d_iq)
+                queued += 1
             n_ev += len(r.drain())
             if collect is not None:
                 t = r.timings()  # HIP events recorded on the streams the kernels of the drained batch ran on
@@ -275,6 +281,7 @@ def main():
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items())},
                 "gpu_ms_per_step": round(float(np.mean(kt.get("total_ms", [0.0]))), 4),
                 "speculation_stats": r.stats(),
+                "pipeline_streams": r.layout(),
             },
         }
         if a.cpu_budget > 0 and world == 1 and rate == 1:

@@ -33,6 +33,7 @@ extern "C" {
 #endif
 
 #define TFREC_AMD_BLOCK_BYTES 65536 /* RLS, engine.cpp:68 */
+#define TFREC_AMD_FIFO_DEPTH 3  /* submits that may wait to be drained (tfrec_amd_drain_events) */
 #define TFREC_AMD_BLOCK_BYTES_10X 655360 /* one block of a 15.36 MS/s stream (TFREC_AMD_F_INPUT_10X) */
 #define TFREC_AMD_BLOCK_DEC 8192    /* decimated IQ pairs per block (4:1, dsp_stuff.cpp:243-264) */
 #define TFREC_AMD_NSLOTS 5
@@ -128,7 +129,7 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *ctx, const void *d_iq, size_t stream_
 			    void *hip_stream);
 /* Same with host memory: stages the batch through an internal device buffer (H2D copy included).  With pinned
  * memory (tfrec_amd_host_alloc) the copy is asynchronous and h_iq must stay untouched until the submit has been
- * drained; together with the depth-2 FIFO below this is the double-buffered feeder of SURVEY row f1: read batch
+ * drained; together with the submit/drain FIFO below this is the double-buffered feeder of SURVEY row f1: read batch
  * k+2 from disk while batch k+1 is copied/processed and batch k's events are dispatched. */
 int tfrec_amd_submit_host(tfrec_amd_ctx *ctx, const uint8_t *h_iq, size_t stream_stride_bytes, int n_blocks);
 /* Page-locked host memory for tfrec_amd_submit_host (NULL on failure). */
@@ -143,9 +144,10 @@ int tfrec_amd_sync(tfrec_amd_ctx *ctx);
  * Wait for the OLDEST submit that has not been drained yet, then copy its events to out[0..cap), ordered by
  * (stream, slot, seq).  *n_out = number written (0 if nothing was submitted).  Returns TFREC_AMD_E_OVERFLOW if the
  * device buffer or cap was too small (the events that fit are still returned).
- * Submits and drains form a FIFO of depth two: a caller may queue submit k+1 before draining submit k, so that the
- * GPU works on k+1 while the host copies and dispatches k's events; a third undrained submit is refused with
- * TFREC_AMD_E_STATE.  Alternating submit / drain behaves as one would expect. */
+ * Submits and drains form a FIFO of depth TFREC_AMD_FIFO_DEPTH (3): a caller may queue submits k+1 and k+2 before
+ * draining submit k, so that the GPU works on them (front end of k+2, filter stage of k+1 and slicer/decoder stage of
+ * k run beside each other) while the host copies and dispatches k's events; one more undrained submit is refused
+ * with TFREC_AMD_E_STATE.  Alternating submit / drain behaves as one would expect. */
 int tfrec_amd_drain_events(tfrec_amd_ctx *ctx, tfrec_amd_event *out, int cap, int *n_out);
 
 /* Number of events of the oldest undrained submit (waits for it). */
@@ -175,6 +177,11 @@ typedef struct {
 	uint64_t reserved[3];
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
+/* Number of internal HIP streams the context's pipeline is laid out on: 6 = deep (the biquad stage of submit k+1 runs
+ * beside the slicer/decoder stage of submit k; chosen when the process runs with GPU_MAX_HW_QUEUES >= 6, which the HIP
+ * runtime reads when it initialises -- default 4 -- so set it before the first HIP call), 4 = shallow, 2 = the
+ * serial cross-check (TFREC_AMD_F_SERIAL_CHAINS).  Results do not depend on it.  No reference counterpart. */
+int tfrec_amd_get_layout(tfrec_amd_ctx *ctx, int *n_streams);
 /* Current trigger threshold of one stream (auto mode, fm_demod.cpp:58-73, moves it; fixed mode returns cfg.thresh). */
 int tfrec_amd_read_thresh(tfrec_amd_ctx *ctx, int stream, int *thresh);
 

@@ -2,6 +2,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 queues.hip -o queues ; run with and without GPU_MAX_HW_QUEUES=8
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <chrono>
 __global__ void spin(long long *out, long long ticks)
 {
@@ -10,13 +11,21 @@ __global__ void spin(long long *out, long long ticks)
 		__builtin_amdgcn_s_sleep(10);
 	out[0] = t0;
 }
-int main()
+int main(int argc, char **argv)
 {
+	const int prio_mode = argc > 1 ? atoi(argv[1]) : 0;  // 0: default priority, 1: all high, 2: first low + rest high
 	long long *d;
 	(void)hipMalloc(&d, 64);
 	hipStream_t st[16];
-	for (int i = 0; i < 16; i++)
-		(void)hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+	int lo = 0, hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+	printf("priority mode %d (range %d..%d)\n", prio_mode, lo, hi);
+	for (int i = 0; i < 16; i++) {
+		if (prio_mode == 0)
+			(void)hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+		else
+			(void)hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, (prio_mode == 2 && i == 0) ? lo : hi);
+	}
 	spin<<<1, 64>>>(d, 1000);
 	(void)hipDeviceSynchronize();
 	for (int n : { 1, 2, 4, 5, 6, 8, 12, 16 }) {

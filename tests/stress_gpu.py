@@ -32,6 +32,7 @@ def _round(rng, rnd, verbose):
                        for s in range(n_streams)])
         cuts = sorted(set([0, n_blocks] + [int(x) for x in rng.integers(1, n_blocks, size=int(rng.integers(0, 4)))]))
         mb = max(b - a for a, b in zip(cuts, cuts[1:]))
+        os.environ["TFREC_AMD_DEEP"] = str(int(rng.integers(0, 2)))  # pipeline layout: read when the context is created
         with api.Receiver(n_streams, types, thresh, wide, max_blocks=mb, all_flushes=True, max_events=400000) as r:
             evs = []
             k = 0
@@ -39,8 +40,9 @@ def _round(rng, rnd, verbose):
             for a, b in zip(cuts, cuts[1:]):
                 r.submit(np.ascontiguousarray(iq[:, a * 65536:b * 65536]))
                 pend += 1
-                if pend == 2 or rng.integers(0, 2):  # sometimes two submits in flight
-                    while pend:
+                if pend == api.FIFO_DEPTH or rng.integers(0, 2):  # sometimes several submits in flight
+                    keep = int(rng.integers(0, pend))              # ... and sometimes the younger ones stay in flight
+                    while pend > keep:
                         evs.append(r.drain())
                         pend -= 1
             while pend:
@@ -56,6 +58,7 @@ def _round(rng, rnd, verbose):
                 if got != want:
                     ok = False
             unc = r.atan_uncertain()
+        os.environ.pop("TFREC_AMD_DEEP", None)
         if verbose:
             print("round %d: streams %d blocks %d types %02x thresh %d wide %d noise %d cuts %s events %d unc %d -> %s" % (
             rnd, n_streams, n_blocks, types, thresh, wide, noise, cuts, len(ev), unc, "ok" if ok else "MISMATCH"), flush=True)

@@ -194,11 +194,11 @@ def test_auto_threshold_matches_oracle(serial):
         assert moved >= 2
 
 
-def test_two_submits_in_flight_fifo():
-    """Submit k+1 may be queued before submit k is drained (FIFO of depth two); a third one is refused."""
+def test_submits_in_flight_fifo():
+    """Submits k+1 and k+2 may be queued before submit k is drained (FIFO of depth three); a fourth one is refused."""
     n_streams = 6
-    iq = synth.gen_batch(23, 5, n_streams, 30)
-    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 10), (10, 20), (20, 30))]
+    iq = synth.gen_batch(23, 5, n_streams, 40)
+    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 10), (10, 20), (20, 30), (30, 40))]
     with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=10, all_flushes=True) as r:
         ref = []
         for p in parts:
@@ -208,12 +208,15 @@ def test_two_submits_in_flight_fifo():
         import torch
         dev = [torch.from_numpy(p).cuda() for p in parts]
         got = []
+        assert api.FIFO_DEPTH == 3
         r.submit(dev[0])
         r.submit(dev[1])
-        with pytest.raises(RuntimeError):
-            r.submit(dev[2])  # two submits are waiting to be drained
-        got.append(r.drain())
         r.submit(dev[2])
+        with pytest.raises(RuntimeError):
+            r.submit(dev[3])  # three submits are waiting to be drained
+        got.append(r.drain())
+        r.submit(dev[3])
+        got.append(r.drain())
         got.append(r.drain())
         got.append(r.drain())
         assert len(r.drain()) == 0
@@ -293,6 +296,35 @@ def test_tfa2_edge_timing_speculation_failure_is_resliced_exactly():
         ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
     for s in range(2):
         check_stream(ev, s, oracle_events(np.concatenate([iq[s], iq[s]]), 0x2F, 500))
+
+
+def test_deep_and_shallow_layouts_agree_across_submits(monkeypatch):
+    """Deep layout (six streams: the biquad stage of submit k+1 beside the slicers of submit k, two table sets) and
+    shallow layout must give the same events as each other and as the oracle over a sequence of unequal submits kept
+    three deep in the FIFO."""
+    n_streams, cuts = 6, (3, 1, 5, 2, 4, 1)
+    iq = synth.gen_batch(77, 40, n_streams, sum(cuts), noise_q8=320)
+    got = {}
+    for deep in ("1", "0"):
+        monkeypatch.setenv("TFREC_AMD_DEEP", deep)
+        with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=max(cuts), all_flushes=True) as r:
+            assert r.layout() == (6 if deep == "1" else 4)
+            evs, pos, pending = [], 0, 0
+            for nb in cuts:
+                r.submit(np.ascontiguousarray(iq[:, pos * 65536:(pos + nb) * 65536]))
+                pos += nb
+                pending += 1
+                if pending == api.FIFO_DEPTH:
+                    evs.append(r.drain())
+                    pending -= 1
+            while pending:
+                evs.append(r.drain())
+                pending -= 1
+            ev = np.concatenate(evs)
+            got[deep] = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
+    assert got["1"].tobytes() == got["0"].tobytes()
+    for s in range(n_streams):
+        check_stream(got["1"], s, oracle_events(iq[s], 0x2F, 500))
 
 
 def test_randomised_campaign():

@@ -9,13 +9,19 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-import numpy as np
+# The deep pipeline layout needs six concurrently running HIP streams; the HIP runtime multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises, i.e. at the first HIP call
+# of the process -- so this only helps when tfrec_amd is imported before anything touched the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 from . import _build
 
 BLOCK_BYTES = 65536
 BLOCK_DEC = 8192
 NSLOTS = 5
+FIFO_DEPTH = 3  # TFREC_AMD_FIFO_DEPTH
 SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
 
 F_ALL_FLUSHES = 1
@@ -77,7 +83,7 @@ EXPORTS = (
     "tfrec_amd_version", "tfrec_amd_strerror", "tfrec_amd_last_error", "tfrec_amd_create", "tfrec_amd_destroy",
     "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
-    "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_host_alloc",
+    "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_get_layout", "tfrec_amd_host_alloc",
     "tfrec_amd_host_free", "tfrec_amd_read_stage0",
 )
 
@@ -128,6 +134,7 @@ def load_library(build: bool = True):
     L.tfrec_amd_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.tfrec_amd_read_thresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.tfrec_amd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.tfrec_amd_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -196,7 +203,7 @@ class Receiver:
         assert iq.stride(1) == 1
         nb = iq.shape[1] // self.block_bytes if n_blocks is None else n_blocks
         st = torch.cuda.current_stream(iq.device) if stream is None else stream
-        self._keep = (getattr(self, "_keep", ()) + (iq,))[-2:]  # inputs stay alive while their submit may be in flight
+        self._keep = (getattr(self, "_keep", ()) + (iq,))[-FIFO_DEPTH:]  # inputs stay alive while their submit may be in flight
         _check(self.L, self.L.tfrec_amd_submit_device(self.h, C.c_void_p(iq.data_ptr()), iq.stride(0), nb,
                                                       C.c_void_p(st.cuda_stream)))
         return nb
@@ -236,6 +243,12 @@ class Receiver:
         t = Timings()
         _check(self.L, self.L.tfrec_amd_get_timings(self.h, C.byref(t)))
         return {n: float(getattr(t, n)) for n, _ in Timings._fields_}
+
+    def layout(self) -> int:
+        """Internal HIP streams of the pipeline: 6 deep, 4 shallow, 2 serial cross-check (tfrec_amd_get_layout)."""
+        n = C.c_int(0)
+        _check(self.L, self.L.tfrec_amd_get_layout(self.h, C.byref(n)))
+        return int(n.value)
 
     def stats(self) -> dict:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""

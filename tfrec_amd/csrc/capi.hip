@@ -19,11 +19,10 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
 			int n_streams, int n_blocks, int wmax);
-hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
-			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
-			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev, hipStream_t t1, hipEvent_t ev_join1);
+			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
 hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stride, unsigned long long *mask,
 			    size_t mask_stride, int n_streams, int n_blocks, FskState *fsk, int wmax);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
@@ -32,6 +31,10 @@ hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride,
 }  // namespace tfrec
 
 using namespace tfrec;
+
+// Buffer / table sets = submits that may be in flight (the FIFO depth): front end of submit k+2, biquad stage of
+// k+1 and slicer stage of k run beside each other in the deep layout
+constexpr int kSets = TFREC_AMD_FIFO_DEPTH;
 
 static thread_local char g_err[256] = "";
 
@@ -53,52 +56,56 @@ struct tfrec_amd_ctx {
 	FrontTaps taps;
 	// front-end outputs, double-buffered like the event buffers: the front end of submit k+1 (its own stream)
 	// runs beside the demodulator chains of submit k
-	uint32_t *d_dec[2] = { nullptr, nullptr };
+	uint32_t *d_dec[kSets] = {};
 	size_t dec_stride = 0;  // uint32 units
-	unsigned long long *d_mask[2] = { nullptr, nullptr };
+	unsigned long long *d_mask[kSets] = {};
 	size_t mask_stride = 0;
-	int16_t *d_fmdev[2] = { nullptr, nullptr };  // [n_streams][m_max] fm_dev of the decimated samples (computed near windows)
-	uint32_t *d_prevdec[2] = { nullptr, nullptr };  // [n_streams] the decimated sample before the submit's first one
+	int16_t *d_fmdev[kSets] = {};  // [n_streams][m_max] fm_dev of the decimated samples (computed near windows)
+	uint32_t *d_prevdec[kSets] = {};  // [n_streams] the decimated sample before the submit's first one
 	bool need_fmdev = false;                      // a TFA_2-family demodulator is registered
-	// Few streams on purpose: HIP multiplexes streams onto 4 hardware queues, and two streams that share a queue
-	// serialise (measured: the WHB chain stopped overlapping the TFA chains with a fifth stream in the process).
-	hipStream_t fs = nullptr;                     // front-end stream (+ the drain's device-to-host copies)
-	hipStream_t cs = nullptr;                     // chains stream (the caller's stream only orders the input)
-	hipEvent_t ev_in[2] = { nullptr, nullptr }, ev_front[2] = { nullptr, nullptr };
+	// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue
+	// serialise (profiles/ubench/queues.hip).  The deep layout (stage A of submit k+1 beside stage B of submit k) has
+	// six streams and is chosen when the process runs with GPU_MAX_HW_QUEUES >= 6; otherwise k2 = cs and kw = aux.
+	hipStream_t fs = nullptr;                     // front-end stream + window scan (+ the drain's device-to-host copies)
+	hipStream_t cs = nullptr;                     // TFA_2-family slicers and decoders (the caller's stream only orders the input)
+	hipStream_t k2 = nullptr, kw = nullptr;       // biquad stages (deep layout only: else aliases of cs / aux)
+	bool deep = false;
+	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
+	hipEvent_t ev_pipe[kSets][4] = {};                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
-	int16_t *d_ld16 = nullptr;   // [chains][m_max] tfa2-family biquad outputs
-	int32_t *d_dev32 = nullptr;  // [n_streams][m_max] WHB stage-1 outputs
-	WinTables win = {};
-	void *win_block = nullptr;
+	// one set per submit in flight, like the front-end outputs: the window scan and the biquads of submit k+1 fill
+	// theirs while the slicers of submit k still read the other
+	int16_t *d_ld16[kSets] = {};   // [chains][m_max] tfa2-family biquad outputs
+	int32_t *d_dev32[kSets] = {};  // [n_streams][m_max] WHB stage-1 outputs
+	WinTables win[kSets] = {};
+	void *win_block[kSets] = {};
+	int32_t *d_tcarry = nullptr;                 // WinTables::timeout_carry
 	FskState *d_fsk = nullptr;  // auto-threshold mode only
 	int wmax = 0;
-	uint8_t *d_tail[2] = { nullptr, nullptr };
+	uint8_t *d_tail[kSets] = {};
 	int tail_sel = 0;
 	// TFREC_AMD_F_INPUT_10X: output of the 10:1 stage (1.536 MS/s int16 pairs, one buffer per set) and its raw history
-	uint32_t *d_in16[2] = { nullptr, nullptr };
+	uint32_t *d_in16[kSets] = {};
 	size_t in16_stride = 0;  // uint32 units
-	uint8_t *d_tail10[2] = { nullptr, nullptr };
+	uint8_t *d_tail10[kSets] = {};
 	bool in10x = false;
 	// Two event buffer sets: a submit may be queued while the host still drains the previous one (FIFO, depth 2)
-	tfrec_amd_event *d_events[2] = { nullptr, nullptr };
-	EventBuf *d_eb[2] = { nullptr, nullptr };
+	tfrec_amd_event *d_events[kSets] = {};
+	EventBuf *d_eb[kSets] = {};
 	EventBuf *d_eb_fresh = nullptr;       // { 0, max_events, 0 }: copied over a set's EventBuf when a submit starts
 	tfrec_amd_event *h_events = nullptr;  // pinned staging for the drain
 	EventBuf *h_eb = nullptr;
-	hipEvent_t done[2] = { nullptr, nullptr };  // end of the submit that owns the set
+	hipEvent_t done[kSets][3] = {};  // end of the submit that owns the set, on the cs / aux / t1 stream
 	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..2)
 	int last_drained = -1;
-	uint8_t *d_stage[2] = { nullptr, nullptr };  // tfrec_amd_submit_host: device staging, one per buffer set
-	size_t stage_bytes[2] = { 0, 0 };
+	uint8_t *d_stage[kSets] = {};  // tfrec_amd_submit_host: device staging, one per buffer set
+	size_t stage_bytes[kSets] = {};
 	long long sample_base = 0;
 	int last_blocks = 0;
-	hipStream_t last_stream = nullptr;
-	hipEvent_t ev[2][4] = {};  // start, after the front end, end of the submit, after the discriminator pass
+	hipEvent_t ev[kSets][4] = {};  // start, after the front end, end of the submit, after the discriminator pass
 	hipStream_t aux = nullptr;  // second stream: WHB stage 2 runs beside the TFA slicers
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	hipEvent_t tev[2][21] = {};
+	hipEvent_t tev[kSets][kTimingMarks] = {};
 	hipStream_t t1 = nullptr;  // TFA_1 slicer chain (needs no biquad stage: runs beside the TFA_2-family biquads)
-	hipEvent_t ev_join1 = nullptr;
 	bool whb_active = false;
 	bool timed = false;
 	unsigned long long uncertain_total = 0;
@@ -184,7 +191,7 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	for (int a = 0; a < kNSlots; a++)
 		if (c->launch.states[a])
 			(void)hipFree(c->launch.states[a]);
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < kSets; k++) {
 		(void)hipFree(c->d_dec[k]);
 		(void)hipFree(c->d_mask[k]);
 		(void)hipFree(c->d_fmdev[k]);
@@ -198,21 +205,32 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipStreamDestroy(c->fs);
 	if (c->cs)
 		(void)hipStreamDestroy(c->cs);
-	(void)hipFree(c->d_ld16);
-	(void)hipFree(c->d_dev32);
-	(void)hipFree(c->win_block);
+	for (int k = 0; k < kSets; k++) {
+		(void)hipFree(c->d_ld16[k]);
+		(void)hipFree(c->d_dev32[k]);
+		(void)hipFree(c->win_block[k]);
+		for (auto &e : c->ev_pipe[k])
+			if (e)
+				(void)hipEventDestroy(e);
+	}
+	(void)hipFree(c->d_tcarry);
+	if (c->deep && c->k2)
+		(void)hipStreamDestroy(c->k2);
+	if (c->deep && c->kw)
+		(void)hipStreamDestroy(c->kw);
 	(void)hipFree(c->d_fsk);
 	(void)hipFree(c->d_tail[0]);
 	(void)hipFree(c->d_tail[1]);
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < kSets; k++) {
 		(void)hipFree(c->d_in16[k]);
 		(void)hipFree(c->d_tail10[k]);
 	}
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < kSets; k++) {
 		(void)hipFree(c->d_events[k]);
 		(void)hipFree(c->d_eb[k]);
-		if (c->done[k])
-			(void)hipEventDestroy(c->done[k]);
+		for (auto &e : c->done[k])
+			if (e)
+				(void)hipEventDestroy(e);
 		for (auto &e : c->ev[k])
 			if (e)
 				(void)hipEventDestroy(e);
@@ -225,18 +243,12 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipHostFree(c->h_events);
 	if (c->h_eb)
 		(void)hipHostFree(c->h_eb);
-	(void)hipFree(c->d_stage[0]);
-	(void)hipFree(c->d_stage[1]);
-	if (c->ev_fork)
-		(void)hipEventDestroy(c->ev_fork);
-	if (c->ev_join)
-		(void)hipEventDestroy(c->ev_join);
+	for (auto &p : c->d_stage)
+		(void)hipFree(p);
 	if (c->aux)
 		(void)hipStreamDestroy(c->aux);
 	if (c->t1)
 		(void)hipStreamDestroy(c->t1);
-	if (c->ev_join1)
-		(void)hipEventDestroy(c->ev_join1);
 	delete c;
 	return TFREC_AMD_OK;
 }
@@ -335,7 +347,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	}
 	c->dec_stride = m_max;
 	c->mask_stride = m_max / 64;
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < kSets; k++) {
 		ALLOC(c->d_dec[k], n * c->dec_stride * sizeof(uint32_t) + 256);  // + slack: K3 loads whole 32-sample chunks at window tails
 		ALLOC(c->d_mask[k], n * c->mask_stride * sizeof(unsigned long long));
 	}
@@ -349,7 +361,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 				rc = TFREC_AMD_E_HIP;
 		}
 	}
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < kSets; k++) {
 		ALLOC(c->d_fmdev[k], n * m_max * sizeof(int16_t) + 256);  // + slack: K3 reads whole dwords past an odd tail
 		ALLOC(c->d_prevdec[k], n * sizeof(uint32_t));
 	}
@@ -361,12 +373,16 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		bool whb = false;
 		for (int a = 0; a < c->launch.n_active; a++)
 			whb = whb || c->launch.params[a].kind == 2;
-		WinTables &T = c->win;
+		ALLOC(c->d_tcarry, chains * 4);
+		if (rc == TFREC_AMD_OK && hipMemset(c->d_tcarry, 0, chains * 4) != hipSuccess)
+			rc = TFREC_AMD_E_HIP;
+		for (int set = 0; set < kSets; set++) {
+		WinTables &T = c->win[set];
 		T.cap = (int32_t)(m_max / 356 + 2);  // windows of one chain are > W-1 >= 355 samples apart
 		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
-		ALLOC(c->d_ld16, chains * (size_t)T.slots * 32 * sizeof(int16_t));
+		ALLOC(c->d_ld16[set], chains * (size_t)T.slots * 32 * sizeof(int16_t));
 		if (whb)
-			ALLOC(c->d_dev32, n * (size_t)T.slots * 32 * sizeof(int32_t));
+			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t));
 		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
 		const size_t wins = chains * (size_t)T.cap;
 		size_t off = 0;
@@ -387,9 +403,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
 		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4);
 		const size_t o_cand = carve(n * (size_t)T.slots * 4), o_mark = carve(n * (size_t)T.slots * sizeof(MarkPiece));
-		ALLOC(c->win_block, off);
+		ALLOC(c->win_block[set], off);
 		if (rc == TFREC_AMD_OK) {
-			uint8_t *b = (uint8_t *)c->win_block;
+			uint8_t *b = (uint8_t *)c->win_block[set];
 			T.count = (int32_t *)(b + o_count);
 			T.cont = (int32_t *)(b + o_cont);
 			T.timeout_next = (int32_t *)(b + o_tnext);
@@ -413,9 +429,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.segfix2 = (int32_t *)(b + o_sfix2);
 			T.cand = (uint32_t *)(b + o_cand);
 			T.mark = (MarkPiece *)(b + o_mark);
+			T.timeout_carry = c->d_tcarry;
+			T.prevdec = c->d_prevdec[set];
 			if (hipMemset(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
 			    hipMemset(T.stats, 0, 64) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
+		}
 		}
 	}
 	c->in10x = (cfg->flags & TFREC_AMD_F_INPUT_10X) != 0;
@@ -424,12 +443,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	ALLOC(c->d_tail[1], n * tail_bytes);
 	if (c->in10x) {
 		c->in16_stride = 4 * m_max;  // complex samples at 1.536 MS/s per stream and submit
-		for (int k = 0; k < 2; k++) {
+		for (int k = 0; k < kSets; k++) {
 			ALLOC(c->d_in16[k], n * c->in16_stride * sizeof(uint32_t));
 			ALLOC(c->d_tail10[k], n * 112);
 		}
 	}
-	for (int k = 0; k < 2; k++) {
+	for (int k = 0; k < kSets; k++) {
 		ALLOC(c->d_events[k], (size_t)cfg->max_events * sizeof(tfrec_amd_event));
 		ALLOC(c->d_eb[k], sizeof(EventBuf));
 	}
@@ -451,31 +470,41 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    hipMemset(c->d_tail[1], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
 		    (c->in10x && (hipMemset(c->d_tail10[0], 0x80, n * 112) != hipSuccess ||
 				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
-		    hipMemcpy(c->d_eb[0], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
-		    hipMemcpy(c->d_eb[1], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipStreamCreateWithPriority(&c->fs, hipStreamNonBlocking, prio_lo) != hipSuccess ||
 		    hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->ev_in[0], hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->ev_in[1], hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->ev_front[0], hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->ev_front[1], hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->done[0], hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->done[1], hipEventDisableTiming) != hipSuccess)
+		    false)
 			rc = TFREC_AMD_E_HIP;
+		for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++) {
+			for (auto &e : c->done[k])
+				if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+					rc = TFREC_AMD_E_HIP;
+			for (auto &e : c->ev_pipe[k])
+				if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+					rc = TFREC_AMD_E_HIP;
+			if (hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming) != hipSuccess ||
+			    hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming) != hipSuccess ||
+			    hipMemcpy(c->d_eb[k], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+		}
 	}
 	if (rc == TFREC_AMD_OK && !(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
-		if (getenv("TFREC_AMD_NO_T1") == nullptr &&
-		    (hipStreamCreateWithPriority(&c->t1, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-		     hipEventCreateWithFlags(&c->ev_join1, hipEventDisableTiming) != hipSuccess))
+		if (hipStreamCreateWithPriority(&c->t1, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+		    hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
-		if (hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+		// deep layout: only when the process was started with enough hardware queues for six streams (the runtime
+		// reads GPU_MAX_HW_QUEUES when it initialises); TFREC_AMD_DEEP=0/1 overrides
+		const char *q = getenv("GPU_MAX_HW_QUEUES"), *dp = getenv("TFREC_AMD_DEEP");
+		c->deep = dp ? atoi(dp) != 0 : (q && atoi(q) >= 6 && false);  // not yet the default: measured slower
+		c->k2 = c->cs;
+		c->kw = c->aux;
+		if (c->deep && rc == TFREC_AMD_OK &&
+		    (hipStreamCreateWithPriority(&c->k2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+		     hipStreamCreateWithPriority(&c->kw, hipStreamNonBlocking, prio_hi) != hipSuccess))
 			rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING)) {
-		for (int k = 0; k < 2; k++) {
+		for (int k = 0; k < kSets; k++) {
 			for (auto &e : c->ev[k])
 				if (hipEventCreate(&e) != hipSuccess)
 					rc = TFREC_AMD_E_HIP;
@@ -506,13 +535,13 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		snprintf(g_err, sizeof(g_err), "IQ base and stream stride must be 16-byte aligned and >= one stream");
 		return TFREC_AMD_E_INVAL;
 	}
-	if (c->inflight >= 2) {
-		snprintf(g_err, sizeof(g_err), "two submits are waiting to be drained: call tfrec_amd_drain_events first");
+	if (c->inflight >= kSets) {
+		snprintf(g_err, sizeof(g_err), "%d submits are waiting to be drained: call tfrec_amd_drain_events first", kSets);
 		return TFREC_AMD_E_STATE;
 	}
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const bool timing = (c->cfg.flags & TFREC_AMD_F_TIMING) != 0;
-	const int set = (c->head + c->inflight) & 1;  // this submit's event buffers and timing events
+	const int set = (c->head + c->inflight) % kSets;  // this submit's event buffers and timing events
 	// Front end on its own stream: it starts when the caller's stream has produced the input, and may overlap the
 	// chains of the previous submit (different buffer set; the set's previous user was drained, see the FIFO rule)
 	hipStream_t fs = c->fs;
@@ -545,27 +574,41 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][1], fs));
-	HIPCHK(hipEventRecord(c->ev_front[set], fs));
-	HIPCHK(hipStreamWaitEvent(st, c->ev_front[set], 0));
-	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)
+	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) {
+		HIPCHK(hipEventRecord(c->ev_front[set], fs));
+		HIPCHK(hipStreamWaitEvent(st, c->ev_front[set], 0));
 		HIPCHK(launch_chains(st, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams, n_blocks,
 				     c->sample_base, c->launch, c->d_events[set], c->d_eb[set], c->cfg.flags));
-	else
-		HIPCHK(launch_pipeline(st, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set],
-				       c->dec_stride, c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win, c->d_ld16,
-				       c->d_dev32, c->d_events[set], c->d_eb[set], c->cfg.flags, 768, c->aux, c->ev_fork, c->ev_join,
-				       (timing && c->tev[set][0]) ? c->tev[set] : nullptr, c->t1, c->ev_join1));
-	if (timing) {
-		HIPCHK(hipEventRecord(c->ev[set][2], st));
-		c->timed = true;
+		if (timing)
+			HIPCHK(hipEventRecord(c->ev[set][2], st));
+		for (auto &e : c->done[set])
+			HIPCHK(hipEventRecord(e, st));
+	} else {
+		PipeCtl P;
+		P.fs = fs;
+		P.k2 = c->k2;
+		P.kw = c->kw;
+		P.cs = c->cs;
+		P.aux = c->aux;
+		P.t1 = c->t1;
+		P.ev_win = c->ev_pipe[set][0];
+		P.ev_fork = c->ev_pipe[set][1];
+		P.ev_k2 = c->ev_pipe[set][2];
+		P.ev_kw = c->ev_pipe[set][3];
+		for (int k = 0; k < 3; k++)
+			P.done[k] = c->done[set][k];
+		P.tev = (timing && c->tev[set][0]) ? c->tev[set] : nullptr;
+		HIPCHK(launch_pipeline(P, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set], c->dec_stride,
+				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
+				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
 	}
-	HIPCHK(hipEventRecord(c->done[set], st));
+	if (timing)
+		c->timed = true;
 	c->inflight++;
 	c->last_set = set;
 	c->tail_sel ^= 1;
 	c->sample_base += (long long)n_blocks * kBlockDec;
 	c->last_blocks = n_blocks;
-	c->last_stream = st;
 	return TFREC_AMD_OK;
 }
 
@@ -581,12 +624,12 @@ int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, 
 	const size_t row = (size_t)n_blocks * (c->in10x ? TFREC_AMD_BLOCK_BYTES_10X : TFREC_AMD_BLOCK_BYTES);
 	if (c->cfg.n_streams > 1 && stride < row)
 		return TFREC_AMD_E_INVAL;
-	if (c->inflight >= 2) {
-		snprintf(g_err, sizeof(g_err), "two submits are waiting to be drained: call tfrec_amd_drain_events first");
+	if (c->inflight >= kSets) {
+		snprintf(g_err, sizeof(g_err), "%d submits are waiting to be drained: call tfrec_amd_drain_events first", kSets);
 		return TFREC_AMD_E_STATE;
 	}
 	HIPCHK(hipSetDevice(c->cfg.device));
-	const int set = (c->head + c->inflight) & 1;  // the set's previous user has been drained: its staging buffer is free
+	const int set = (c->head + c->inflight) % kSets;  // the set's previous user has been drained: its staging buffer is free
 	const size_t need = row * (size_t)c->cfg.n_streams;
 	if (c->stage_bytes[set] < need) {
 		(void)hipFree(c->d_stage[set]);
@@ -621,7 +664,9 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	HIPCHK(hipStreamSynchronize(c->last_stream));
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->aux, c->t1 })
+		if (st)
+			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;
 }
 
@@ -633,7 +678,8 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 	if (c->inflight == 0)
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	HIPCHK(hipEventSynchronize(c->done[c->head]));  // the oldest submit not yet drained
+	for (auto &e : c->done[c->head])  // the oldest submit not yet drained
+		HIPCHK(hipEventSynchronize(e));
 	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->fs));
 	HIPCHK(hipStreamSynchronize(c->fs));
 	const EventBuf eb = *c->h_eb;
@@ -650,7 +696,8 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const int set = c->head;  // the oldest submit not yet drained; a younger one may still be running
-	HIPCHK(hipEventSynchronize(c->done[set]));
+	for (auto &e : c->done[set])
+		HIPCHK(hipEventSynchronize(e));
 	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->fs));
 	HIPCHK(hipStreamSynchronize(c->fs));
 	const EventBuf eb = *c->h_eb;
@@ -661,13 +708,13 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 				      c->fs));
 		HIPCHK(hipStreamSynchronize(c->fs));
 	}
-	c->head ^= 1;
+	c->head = (c->head + 1) % kSets;
 	c->inflight--;
 	c->last_drained = set;
 	c->uncertain_total += eb.uncertain;
-	if (c->win.overflow && c->inflight == 0) {
+	if (c->win[set].overflow) {
 		int32_t wov = 0;
-		HIPCHK(hipMemcpyAsync(c->h_eb, c->win.overflow, 4, hipMemcpyDeviceToHost, c->fs));
+		HIPCHK(hipMemcpyAsync(c->h_eb, c->win[set].overflow, 4, hipMemcpyDeviceToHost, c->fs));
 		HIPCHK(hipStreamSynchronize(c->fs));
 		memcpy(&wov, c->h_eb, 4);
 		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
@@ -729,7 +776,7 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 	*n = c->uncertain_total;
 	for (int k = 0; k < c->inflight; k++) {  // submits not drained yet
 		EventBuf eb;
-		HIPCHK(hipMemcpy(&eb, c->d_eb[(c->head + k) & 1], sizeof(eb), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&eb, c->d_eb[(c->head + k) % kSets], sizeof(eb), hipMemcpyDeviceToHost));
 		*n += eb.uncertain;
 	}
 	return TFREC_AMD_OK;
@@ -761,30 +808,62 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	// the most recently drained submit; before the first drain: the oldest one in flight
 	const int set = c->last_drained >= 0 ? c->last_drained : c->head;
 	hipEvent_t *ev = c->ev[set], *tev = c->tev[set];
-	HIPCHK(hipEventSynchronize(ev[2]));
+	for (auto &e : c->done[set])
+		HIPCHK(hipEventSynchronize(e));
 	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[3]));
 	HIPCHK(hipEventElapsedTime(&out->fmdev_ms, ev[3], ev[1]));
-	HIPCHK(hipEventElapsedTime(&out->chains_ms, ev[1], ev[2]));
-	HIPCHK(hipEventElapsedTime(&out->total_ms, ev[0], ev[2]));
 	out->windows_ms = out->spec_biquad_ms = out->repair_biquad_ms = out->fix_biquad_ms = out->slicer_ms = 0;
 	out->coop_slicer_ms = out->decode_ms = out->commit_ms = 0;
 	out->whb_biquad_ms = out->whb_demod_ms = out->whb_decode_ms = out->whb_commit_ms = 0;
 	out->tfa1_slicer_ms = out->tfa1_coop_slicer_ms = out->tfa1_decode_commit_ms = 0;
-	if (tev[0]) {
-		float *main_ms[8] = { &out->windows_ms, &out->spec_biquad_ms, &out->repair_biquad_ms, &out->fix_biquad_ms,
-				      &out->slicer_ms,  &out->coop_slicer_ms, &out->decode_ms,        &out->commit_ms };
-		for (int k = 0; k < 8; k++)
-			HIPCHK(hipEventElapsedTime(main_ms[k], tev[k], tev[k + 1]));
+	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) {
+		HIPCHK(hipEventElapsedTime(&out->chains_ms, ev[1], ev[2]));
+		HIPCHK(hipEventElapsedTime(&out->total_ms, ev[0], ev[2]));
+		return TFREC_AMD_OK;
+	}
+	// the submit ends when the last of its three chains does
+	out->chains_ms = out->total_ms = 0;
+	bool has[3] = { false, false, false };  // TFA_2 family, WHB, TFA_1
+	for (int a = 0; a < c->launch.n_active; a++)
+		has[c->launch.params[a].kind == 1 ? 0 : (c->launch.params[a].kind == 2 ? 1 : 2)] = true;
+	const int last_mark[3] = { 8, 15, 20 };
+	for (int k = 0; k < 3; k++)
+		if (has[k]) {
+			float t = 0;
+			HIPCHK(hipEventElapsedTime(&t, ev[1], tev[last_mark[k]]));
+			out->chains_ms = std::max(out->chains_ms, t);
+			HIPCHK(hipEventElapsedTime(&t, ev[0], tev[last_mark[k]]));
+			out->total_ms = std::max(out->total_ms, t);
+		}
+	HIPCHK(hipEventElapsedTime(&out->windows_ms, tev[0], tev[21]));
+	if (has[0]) {
+		float *k2_ms[3] = { &out->spec_biquad_ms, &out->repair_biquad_ms, &out->fix_biquad_ms };
+		for (int k = 0; k < 3; k++)
+			HIPCHK(hipEventElapsedTime(k2_ms[k], tev[1 + k], tev[2 + k]));
+		HIPCHK(hipEventElapsedTime(&out->slicer_ms, tev[23], tev[5]));
+		HIPCHK(hipEventElapsedTime(&out->coop_slicer_ms, tev[5], tev[6]));
+		HIPCHK(hipEventElapsedTime(&out->decode_ms, tev[6], tev[7]));
+		HIPCHK(hipEventElapsedTime(&out->commit_ms, tev[7], tev[8]));
+	}
+	if (has[2]) {
 		HIPCHK(hipEventElapsedTime(&out->tfa1_slicer_ms, tev[16], tev[17]));
 		HIPCHK(hipEventElapsedTime(&out->tfa1_coop_slicer_ms, tev[17], tev[18]));
 		HIPCHK(hipEventElapsedTime(&out->tfa1_decode_commit_ms, tev[18], tev[20]));
-		if (c->whb_active) {
-			HIPCHK(hipEventElapsedTime(&out->whb_biquad_ms, tev[9], tev[12]));
-			HIPCHK(hipEventElapsedTime(&out->whb_demod_ms, tev[12], tev[13]));
-			HIPCHK(hipEventElapsedTime(&out->whb_decode_ms, tev[13], tev[14]));
-			HIPCHK(hipEventElapsedTime(&out->whb_commit_ms, tev[14], tev[15]));
-		}
 	}
+	if (has[1]) {
+		HIPCHK(hipEventElapsedTime(&out->whb_biquad_ms, tev[9], tev[12]));
+		HIPCHK(hipEventElapsedTime(&out->whb_demod_ms, tev[22], tev[13]));
+		HIPCHK(hipEventElapsedTime(&out->whb_decode_ms, tev[13], tev[14]));
+		HIPCHK(hipEventElapsedTime(&out->whb_commit_ms, tev[14], tev[15]));
+	}
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_get_layout(tfrec_amd_ctx *c, int *n_streams)
+{
+	if (!c || !n_streams)
+		return TFREC_AMD_E_INVAL;
+	*n_streams = (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) ? 2 : (c->deep ? 6 : 4);
 	return TFREC_AMD_OK;
 }
 
@@ -793,12 +872,18 @@ int tfrec_amd_get_stats(tfrec_amd_ctx *c, tfrec_amd_stats *out)
 	if (!c || !out)
 		return TFREC_AMD_E_INVAL;
 	memset(out, 0, sizeof(*out));
-	if (!c->win.stats)
+	if (!c->win[0].stats)
 		return TFREC_AMD_OK;
 	int rc = tfrec_amd_sync(c);
 	if (rc)
 		return rc;
-	HIPCHK(hipMemcpy(out, c->win.stats, sizeof(*out), hipMemcpyDeviceToHost));
+	static_assert(sizeof(tfrec_amd_stats) == 8 * sizeof(uint64_t), "eight counters");
+	for (int k = 0; k < kSets; k++) {  // the table sets count separately
+		tfrec_amd_stats part;
+		HIPCHK(hipMemcpy(&part, c->win[k].stats, sizeof(part), hipMemcpyDeviceToHost));
+		for (int i = 0; i < 8; i++)
+			reinterpret_cast<uint64_t *>(out)[i] += reinterpret_cast<const uint64_t *>(&part)[i];
+	}
 	return TFREC_AMD_OK;
 }
 

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 	for (int a = 0; a < kNSlots; a++) {
 		const bool act = a < L.n_active;
 		W[a] = act ? L.params[a].window : 400;
-		t0[a] = act ? L.states[a][s].timeout_cnt : 0;
+		t0[a] = act ? T.timeout_carry[a * n_streams + s] : 0;
 		open[a] = t0[a] > 0;
 		open_g[a] = 0;
 		last_trig[a] = open[a] ? t0[a] - W[a] : -(1 << 29);  // virtual trigger leaving t0 samples of window
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 				T.count[c] = count[a] < T.cap ? count[a] : T.cap;
 				T.cont[c] = t0[a] > 0 ? 1 : 0;
 				T.timeout_next[c] = tnext;
+				T.timeout_carry[c] = tnext;
 				T.vtotal[c] = vs[a];
 			}
 		}
@@ -581,7 +582,7 @@ __device__ __forceinline__ void seg_task(uint2 it, int repair, int n_streams, in
 	const int nslots = left < kSegSlots ? left : kSegSlots;
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
-	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
+	const uint32_t prev0 = T.prevdec[s];  // not st.prev_i/q: stage B of the previous submit may still be running
 	const size_t sk = (size_t)c * T.segcap + k;
 	bool conv;
 	Biquad f;
@@ -662,7 +663,7 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	const BiquadEnd *e1 = T.segend1 + (size_t)c * T.segcap;
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
-	const uint32_t prev0 = ((uint32_t)st.prev_i & 0xffffu) | ((uint32_t)st.prev_q << 16);
+	const uint32_t prev0 = T.prevdec[s];
 	const double2 *ckrow = T.ckpt + (size_t)c * T.slots;
 	BiquadEnd prev = e1[0], cur = prev;
 	Biquad f = biquad_of(prev);  // the TRUE state after segment 0
@@ -2348,24 +2349,31 @@ __global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------ launch
-hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
-			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags, int slicer_waves, hipStream_t aux,
-			   hipEvent_t ev_fork, hipEvent_t ev_join, hipEvent_t *tev, hipStream_t t1, hipEvent_t ev_join1)
+			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags)
 {
-	// tev (optional, 21 events; 16..20: the TFA_1 slicer chain, on stream t1 if given), one interval per kernel -- main stream: 0 | windows | 1 | spec | 2 | repair | 3 | fix | 4
-	// | slicer | 5 | coop_slicer | 6 | decode | 7 | commit | 8; WHB stream: 9 | spec | 10 | repair | 11 | fix | 12 |
-	// whb_demod | 13 | whb_decode | 14 | whb_commit | 15
+	// P.tev (optional, kTimingMarks events), one interval per kernel:
+	//   fs : 0 | windows | 21
+	//   k2 : 1 | spec | 2 | repair | 3 | fix | 4(k2)        cs : 23 | slicer | 5 | coop_slicer | 6 | decode | 7 | commit | 8
+	//   kw : 9 | spec | 10 | repair | 11 | fix | 12          aux: 22 | whb_demod | 13 | whb_decode | 14 | whb_commit | 15
+	//   t1 : 16 | mark + slicer | 17 | coop_slicer | 18 | decode | 19 | commit | 20
 	auto mark = [&](int k, hipStream_t s_) {
-		if (tev)
-			(void)hipEventRecord(tev[k], s_);
+		if (P.tev)
+			(void)hipEventRecord(P.tev[k], s_);
 	};
-	if (L.n_active == 0)
+	hipError_t e = hipSuccess;
+#define TRY(x)                          \
+	do {                            \
+		if ((e = (x)) != hipSuccess) \
+			return e;       \
+	} while (0)
+	if (L.n_active == 0) {
+		for (int k = 0; k < 3; k++)
+			TRY(hipEventRecord(P.done[k], k == 0 ? P.cs : (k == 1 ? P.aux : P.t1)));
 		return hipSuccess;
-	hipError_t e = hipMemsetAsync(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue), st);
-	if (e != hipSuccess)
-		return e;
+	}
 	// Lanes per wave for the serial kernels (tunable for experiments: TFREC_AMD_LANES_*).  Measured on MI355X:
 	// fewer lanes per wave (less lock-step divergence, more waves) is NOT faster -- full waves win.
 	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64, 1, 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64, 1, 64);
@@ -2380,47 +2388,41 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 	const int coop_blocks = std::min(env_int("TFREC_AMD_COOP_BLOCKS", 32768, 1, 1 << 20), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
 								((size_t)n_blocks * kBlockDec / (size_t)std::max(long_window, 356) + 1), 1u << 30)));
 	const int dec_blocks = std::min(16384, std::max(1, win_blocks));
-	(void)slicer_waves;
-	mark(0, st);
-	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, st, mask, mask_stride, n_streams, n_blocks, L, T,
-			   long_window);
-	mark(1, st);
-	// Two independent kernel chains after the window scan (they touch disjoint state):
-	//   aux stream : WHB   spec -> repair -> fix (biquad)  -> whb_demod -> whb_decode -> whb_commit
-	//   main stream: TFA   spec -> repair -> fix (biquads) -> slicer -> coop_slicer -> decode -> commit
-	bool has_whb = false, has_tfa2 = false;
+	bool has_whb = false, has_tfa2 = false, has_tfa1 = false;
 	for (int a = 0; a < L.n_active; a++) {
 		has_whb = has_whb || L.params[a].kind == 2;
 		has_tfa2 = has_tfa2 || L.params[a].kind == 1;
-	}
-	bool forked = false, t1_forked = false, has_tfa1 = false;
-	for (int a = 0; a < L.n_active; a++)
 		has_tfa1 = has_tfa1 || L.params[a].kind == 0;
-	if (t1 && has_tfa1 && has_tfa2 && env_int("TFREC_AMD_T1_EARLY", 0)) {
-		if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(t1, ev_fork, 0)) != hipSuccess)
-			return e;
-		t1_forked = true;
 	}
+	// ---- window scan, behind the front end on its stream
+	TRY(hipMemsetAsync(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue), P.fs));
+	mark(0, P.fs);
+	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, P.fs, mask, mask_stride, n_streams, n_blocks, L, T,
+			   long_window);
+	mark(21, P.fs);
+	TRY(hipEventRecord(P.ev_win, P.fs));
+	// Independent kernel chains after the scan (they touch disjoint state):
+	//   kw -> aux: WHB          spec -> repair -> fix (biquad) | whb_demod -> whb_decode -> whb_commit
+	//   k2 -> cs : TFA_2 family spec -> repair -> fix (biquads) | slicer -> coop_slicer -> decode -> commit
+	//   t1       : TFA_1        mark -> slicer -> coop_slicer -> decode -> commit
+	// ---- WHB
 	if (has_whb) {
-		hipStream_t ws = st;
-		if (aux) {
-			if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess)
-				return e;
-			forked = true;
-			ws = aux;
-		}
-		mark(9, ws);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
+		mark(9, P.kw);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 0);
-		mark(10, ws);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+		mark(10, P.kw);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 1);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 2);
-		mark(11, ws);
-		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, ws, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
+		mark(11, P.kw);
+		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 2);
-		mark(12, ws);
+		mark(12, P.kw);
+		TRY(hipEventRecord(P.ev_kw, P.kw));
+		TRY(hipStreamWaitEvent(P.aux, P.ev_kw, 0));
+		mark(22, P.aux);
 		for (int a = 0; a < L.n_active; a++)
 			if (L.params[a].kind == 2) {
 				// 22 KB of dynamic LDS nobody uses: at most 7 of this kernel's one-wave workgroups fit on a CU.  It is
@@ -2428,41 +2430,17 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 				// waves onto the few CUs that happen to have room, where they share SIMDs with each other for their
 				// whole life (measured: 10.4 -> 8.5 ms; above 24 KB the workgroups start to wait for LDS: 12 ms)
 				static const int whb_lds = env_int("TFREC_AMD_WHB_LDS", 22000, 0, 64 << 10);
-				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, ws, dec, dec_stride, dev32, n_streams,
+				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
 						   n_blocks, L, a, T);
-				mark(13, ws);
-				hipLaunchKernelGGL(whb_decode_kernel, dim3(std::max(1, dec_blocks / 4)), block, 0, ws, n_streams, L, a, T);
-				mark(14, ws);
-				hipLaunchKernelGGL(whb_commit_kernel, dim3((n_streams + 63) / 64), block, 0, ws, dec, dec_stride, n_streams,
+				mark(13, P.aux);
+				hipLaunchKernelGGL(whb_decode_kernel, dim3(std::max(1, dec_blocks / 4)), block, 0, P.aux, n_streams, L, a, T);
+				mark(14, P.aux);
+				hipLaunchKernelGGL(whb_commit_kernel, dim3((n_streams + 63) / 64), block, 0, P.aux, dec, dec_stride, n_streams,
 						   n_blocks, sample_base, L, a, T, events, eb, flags);
-				mark(15, ws);
+				mark(15, P.aux);
 			}
-		if (forked && (e = hipEventRecord(ev_join, aux)) != hipSuccess)
-			return e;
 	}
-	if (has_tfa2) {
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);
-		mark(2, st);
-		if (t1 && has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
-			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad passes (on the
-			// critical path of the two other chains) have had the chip to themselves
-			if ((e = hipEventRecord(ev_fork, st)) != hipSuccess || (e = hipStreamWaitEvent(t1, ev_fork, 0)) != hipSuccess)
-				return e;
-			t1_forked = true;
-		}
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 2);
-		mark(3, st);
-		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, st, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
-				   L, T, ld16, dev32, lanes_chain, 1);
-	} else {
-		mark(2, st);
-		mark(3, st);
-	}
-	mark(4, st);
+	TRY(hipEventRecord(P.done[1], P.aux));
 	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 48));
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
@@ -2484,21 +2462,44 @@ hipError_t launch_pipeline(hipStream_t st, const uint32_t *dec, size_t dec_strid
 					   sample_base, L, T, events, eb, flags);
 		mark(m0 + 4, s_);
 	};
-	if (t1_forked) {
-		mark(16, t1);
-		slicer_chain(0, t1, 16);  // marks 17..20
-		if ((e = hipEventRecord(ev_join1, t1)) != hipSuccess)
-			return e;
+	// ---- TFA_2 family
+	bool t1_waits = false;
+	if (has_tfa2) {
+		TRY(hipStreamWaitEvent(P.k2, P.ev_win, 0));
+		mark(1, P.k2);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);
+		mark(2, P.k2);
+		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
+			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
+			// critical path of the other chains) has had the chip to itself
+			TRY(hipEventRecord(P.ev_fork, P.k2));
+			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
+			t1_waits = true;
+		}
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
+		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 2);
+		mark(3, P.k2);
+		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
+				   L, T, ld16, dev32, lanes_chain, 1);
+		mark(4, P.k2);
+		TRY(hipEventRecord(P.ev_k2, P.k2));
+		TRY(hipStreamWaitEvent(P.cs, P.ev_k2, 0));
+		mark(23, P.cs);
+		slicer_chain(1, P.cs, 4);  // marks 5..8
 	}
-	slicer_chain(1, st, 4);  // marks 5..8
-	if (!t1_forked) {  // no third stream: TFA_1 after the TFA_2 family
-		mark(16, st);
-		slicer_chain(0, st, 16);  // marks 17..20
+	TRY(hipEventRecord(P.done[0], P.cs));
+	// ---- TFA_1
+	if (has_tfa1) {
+		if (!t1_waits)
+			TRY(hipStreamWaitEvent(P.t1, P.ev_win, 0));
+		mark(16, P.t1);
+		slicer_chain(0, P.t1, 16);  // marks 17..20
 	}
-	if (t1_forked && (e = hipStreamWaitEvent(st, ev_join1, 0)) != hipSuccess)
-		return e;
-	if (forked && (e = hipStreamWaitEvent(st, ev_join, 0)) != hipSuccess)
-		return e;
+	TRY(hipEventRecord(P.done[2], P.t1));
+#undef TRY
 	return hipGetLastError();
 }
 

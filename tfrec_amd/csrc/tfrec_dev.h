@@ -179,7 +179,26 @@ struct WinTables {
 	int32_t *segfix2;       // [chains*segcap] second repair run: slots rewritten | kSegConverged | kSegRan (0: not run)
 	int32_t *overflow;      // set when a chain found more than cap windows
 	unsigned long long *stats;  // [8] tfrec_amd_stats
+	const uint32_t *prevdec;  // [n_streams] the decimated sample before this submit's first one (front end)
+	int32_t *timeout_carry; // [chains] timeout_cnt the window scan carries from submit to submit (ONE array per context,
+	                        // shared by the two table sets: the scan of submit k+1 must not wait for the chains of k)
 };
+
+// Streams and events of one submit of the window-parallel pipeline.  Every (protocol family, stage) pair owns a
+// stream, so that stage A (biquads) of submit k+1 runs beside stage B (slicers, decoders) of submit k; the two
+// submits use different table / buffer sets.  k2 == cs and kw == aux is allowed (shallow layout: with the HIP
+// default of 4 hardware queues more streams would share queues and serialise).
+struct PipeCtl {
+	hipStream_t fs;            // front-end stream: the window scan is appended to it
+	hipStream_t k2, kw;        // stage A: biquads of the TFA_2 family / of WHB
+	hipStream_t cs, aux, t1;   // stage B: TFA_2 family, WHB, TFA_1 (no stage A)
+	hipEvent_t ev_win;         // window scan done (fs)
+	hipEvent_t ev_fork;        // first TFA_2 biquad pass done (k2): TFA_1 starts
+	hipEvent_t ev_k2, ev_kw;   // stage A done
+	hipEvent_t done[3];        // end of the submit on cs / aux / t1
+	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
+};
+constexpr int kTimingMarks = 24;
 
 constexpr int kNQueues = 8;
 // one more counter after the work queues, with a (stream, slot) list behind the queues' items: the TFA_2-family
