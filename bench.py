@@ -24,10 +24,7 @@ import sys
 import tempfile
 import time
 
-# before anything initialises HIP: six streams of the deep pipeline layout need more than the default 4 hardware queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import numpy as np  # noqa: E402
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -177,10 +177,10 @@ typedef struct {
 	uint64_t reserved[3];
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
-/* Number of internal HIP streams the context's pipeline is laid out on: 6 = deep (the biquad stage of submit k+1 runs
- * beside the slicer/decoder stage of submit k; chosen when the process runs with GPU_MAX_HW_QUEUES >= 6, which the HIP
- * runtime reads when it initialises -- default 4 -- so set it before the first HIP call), 4 = shallow, 2 = the
- * serial cross-check (TFREC_AMD_F_SERIAL_CHAINS).  Results do not depend on it.  No reference counterpart. */
+/* Number of internal HIP streams the context's pipeline is laid out on: 6 = deep (default: the filter stage of submit
+ * k+1 runs beside the slicer/decoder stage of submit k), 4 = shallow (environment TFREC_AMD_DEEP=0 when the context is
+ * created), 2 = the serial cross-check (TFREC_AMD_F_SERIAL_CHAINS).  Results do not depend on it.  No reference
+ * counterpart. */
 int tfrec_amd_get_layout(tfrec_amd_ctx *ctx, int *n_streams);
 /* Current trigger threshold of one stream (auto mode, fm_demod.cpp:58-73, moves it; fixed mode returns cfg.thresh). */
 int tfrec_amd_read_thresh(tfrec_amd_ctx *ctx, int stream, int *thresh);

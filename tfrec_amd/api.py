@@ -9,12 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-# The deep pipeline layout needs six concurrently running HIP streams; the HIP runtime multiplexes streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it initialises, i.e. at the first HIP call
-# of the process -- so this only helps when tfrec_amd is imported before anything touched the GPU.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import numpy as np  # noqa: E402
+import numpy as np
 
 from . import _build
 

@@ -63,13 +63,19 @@ struct tfrec_amd_ctx {
 	int16_t *d_fmdev[kSets] = {};  // [n_streams][m_max] fm_dev of the decimated samples (computed near windows)
 	uint32_t *d_prevdec[kSets] = {};  // [n_streams] the decimated sample before the submit's first one
 	bool need_fmdev = false;                      // a TFA_2-family demodulator is registered
-	// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue
-	// serialise (profiles/ubench/queues.hip).  The deep layout (stage A of submit k+1 beside stage B of submit k) has
-	// six streams and is chosen when the process runs with GPU_MAX_HW_QUEUES >= 6; otherwise k2 = cs and kw = aux.
+	// HIP multiplexes the streams of one priority onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams
+	// that share a queue serialise (profiles/ubench/queues.hip).  The deep layout (stage A of submit k+1 beside stage B
+	// of submit k) has six streams in two priority classes (see cp below); the shallow one has k2 = cs and kw = aux.
 	hipStream_t fs = nullptr;                     // front-end stream + window scan (+ the drain's device-to-host copies)
 	hipStream_t cs = nullptr;                     // TFA_2-family slicers and decoders (the caller's stream only orders the input)
 	hipStream_t k2 = nullptr, kw = nullptr;       // biquad stages (deep layout only: else aliases of cs / aux)
+	// The drain's device-to-host copies must not queue behind the work of younger submits, so they need a hardware
+	// queue of their own.  The runtime keeps one pool of hardware queues PER PRIORITY: fs / cs / aux / t1 are the
+	// high-priority streams, and cp (with k2 / kw in the deep layout) has normal priority -- no pool holds more than
+	// four streams, whatever GPU_MAX_HW_QUEUES is.
+	hipStream_t cp = nullptr;
 	bool deep = false;
+	bool fmdev_k2 = false;                        // the discriminator pass runs at the head of k2, not behind the front end
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
 	hipEvent_t ev_pipe[kSets][4] = {};                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
@@ -203,6 +209,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	}
 	if (c->fs)
 		(void)hipStreamDestroy(c->fs);
+	if (c->cp)
+		(void)hipStreamDestroy(c->cp);
 	if (c->cs)
 		(void)hipStreamDestroy(c->cs);
 	for (int k = 0; k < kSets; k++) {
@@ -458,10 +466,13 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	    (hipHostMalloc((void **)&c->h_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
 	     hipHostMalloc((void **)&c->h_eb, sizeof(EventBuf), hipHostMallocDefault) != hipSuccess))
 		rc = TFREC_AMD_E_NOMEM;
-	// The latency-bound chains get the high-priority queues; the throughput-bound front end of the NEXT submit,
-	// which runs beside them, fills what they leave free.
+	// Every pipeline stream except the biquad stages runs at high priority.  With the front end at low priority
+	// ("fill what the latency-bound chains leave free") its kernel stretched from 3 to 11 ms beside the chains and,
+	// with three submits in flight, became the longest stage of all: 13.4 ms per batch instead of 11.7.
 	int prio_lo = 0, prio_hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+	const int prio_fs = getenv("TFREC_AMD_PRIO_FS") ? atoi(getenv("TFREC_AMD_PRIO_FS")) : prio_hi;
+	(void)prio_lo;
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb = { 0u, (uint32_t)cfg->max_events, 0ull };
@@ -471,7 +482,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    (c->in10x && (hipMemset(c->d_tail10[0], 0x80, n * 112) != hipSuccess ||
 				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
-		    hipStreamCreateWithPriority(&c->fs, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+		    hipStreamCreateWithPriority(&c->fs, hipStreamNonBlocking, prio_fs) != hipSuccess ||
+		    hipStreamCreateWithFlags(&c->cp, hipStreamNonBlocking) != hipSuccess ||
 		    hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio_hi) != hipSuccess ||
 		    false)
 			rc = TFREC_AMD_E_HIP;
@@ -492,15 +504,15 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		if (hipStreamCreateWithPriority(&c->t1, hipStreamNonBlocking, prio_hi) != hipSuccess ||
 		    hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
-		// deep layout: only when the process was started with enough hardware queues for six streams (the runtime
-		// reads GPU_MAX_HW_QUEUES when it initialises); TFREC_AMD_DEEP=0/1 overrides
-		const char *q = getenv("GPU_MAX_HW_QUEUES"), *dp = getenv("TFREC_AMD_DEEP");
-		c->deep = dp ? atoi(dp) != 0 : (q && atoi(q) >= 6 && false);  // not yet the default: measured slower
+		// deep layout (default; TFREC_AMD_DEEP=0 selects the shallow one): the biquad stages get streams of their own
+		const char *dp = getenv("TFREC_AMD_DEEP");
+		c->deep = dp ? atoi(dp) != 0 : true;
+		c->fmdev_k2 = getenv("TFREC_AMD_FMDEV_K2") ? atoi(getenv("TFREC_AMD_FMDEV_K2")) != 0 : false;
 		c->k2 = c->cs;
 		c->kw = c->aux;
 		if (c->deep && rc == TFREC_AMD_OK &&
-		    (hipStreamCreateWithPriority(&c->k2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-		     hipStreamCreateWithPriority(&c->kw, hipStreamNonBlocking, prio_hi) != hipSuccess))
+		    (hipStreamCreateWithFlags(&c->k2, hipStreamNonBlocking) != hipSuccess ||
+		     hipStreamCreateWithFlags(&c->kw, hipStreamNonBlocking) != hipSuccess))
 			rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING)) {
@@ -569,7 +581,8 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 					n_blocks, c->d_fsk, c->wmax));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][3], fs));
-	if (c->need_fmdev)  // FM discriminator of the samples near trigger windows (after the mask is final)
+	const bool fmdev_k2 = c->need_fmdev && c->fmdev_k2 && !(c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS);
+	if (c->need_fmdev && !fmdev_k2)  // FM discriminator of the samples near trigger windows (after the mask is final)
 		HIPCHK(launch_fmdev(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_prevdec[set],
 				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax));
 	if (timing)
@@ -598,6 +611,9 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		for (int k = 0; k < 3; k++)
 			P.done[k] = c->done[set][k];
 		P.tev = (timing && c->tev[set][0]) ? c->tev[set] : nullptr;
+		P.fmdev_wmax = fmdev_k2 ? c->wmax : 0;
+		P.fmdev_out = c->d_fmdev[set];
+		P.prevdec = c->d_prevdec[set];
 		HIPCHK(launch_pipeline(P, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set], c->dec_stride,
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
 				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
@@ -664,7 +680,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->aux, c->t1 })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->aux, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;
@@ -680,8 +696,8 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 	HIPCHK(hipSetDevice(c->cfg.device));
 	for (auto &e : c->done[c->head])  // the oldest submit not yet drained
 		HIPCHK(hipEventSynchronize(e));
-	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->fs));
-	HIPCHK(hipStreamSynchronize(c->fs));
+	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->cp));
+	HIPCHK(hipStreamSynchronize(c->cp));
 	const EventBuf eb = *c->h_eb;
 	*n = (int)std::min(eb.count, eb.capacity);
 	return eb.count > eb.capacity ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
@@ -698,15 +714,15 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	const int set = c->head;  // the oldest submit not yet drained; a younger one may still be running
 	for (auto &e : c->done[set])
 		HIPCHK(hipEventSynchronize(e));
-	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->fs));
-	HIPCHK(hipStreamSynchronize(c->fs));
+	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->cp));
+	HIPCHK(hipStreamSynchronize(c->cp));
 	const EventBuf eb = *c->h_eb;
 	const uint32_t have = std::min(eb.count, eb.capacity);
 	bool overflow = eb.count > eb.capacity;
 	if (have) {
 		HIPCHK(hipMemcpyAsync(c->h_events, c->d_events[set], (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost,
-				      c->fs));
-		HIPCHK(hipStreamSynchronize(c->fs));
+				      c->cp));
+		HIPCHK(hipStreamSynchronize(c->cp));
 	}
 	c->head = (c->head + 1) % kSets;
 	c->inflight--;
@@ -714,8 +730,8 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	c->uncertain_total += eb.uncertain;
 	if (c->win[set].overflow) {
 		int32_t wov = 0;
-		HIPCHK(hipMemcpyAsync(c->h_eb, c->win[set].overflow, 4, hipMemcpyDeviceToHost, c->fs));
-		HIPCHK(hipStreamSynchronize(c->fs));
+		HIPCHK(hipMemcpyAsync(c->h_eb, c->win[set].overflow, 4, hipMemcpyDeviceToHost, c->cp));
+		HIPCHK(hipStreamSynchronize(c->cp));
 		memcpy(&wov, c->h_eb, 4);
 		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
 			snprintf(g_err, sizeof(g_err), "window table overflow");
@@ -812,6 +828,8 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 		HIPCHK(hipEventSynchronize(e));
 	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[3]));
 	HIPCHK(hipEventElapsedTime(&out->fmdev_ms, ev[3], ev[1]));
+	if (c->need_fmdev && c->fmdev_k2 && !(c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS))
+		HIPCHK(hipEventElapsedTime(&out->fmdev_ms, tev[24], tev[25]));
 	out->windows_ms = out->spec_biquad_ms = out->repair_biquad_ms = out->fix_biquad_ms = out->slicer_ms = 0;
 	out->coop_slicer_ms = out->decode_ms = out->commit_ms = 0;
 	out->whb_biquad_ms = out->whb_demod_ms = out->whb_decode_ms = out->whb_commit_ms = 0;

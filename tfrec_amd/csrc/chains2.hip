@@ -2349,6 +2349,10 @@ __global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------ launch
+hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
+			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
+			int n_streams, int n_blocks, int wmax);
+
 hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
@@ -2358,6 +2362,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	//   fs : 0 | windows | 21
 	//   k2 : 1 | spec | 2 | repair | 3 | fix | 4(k2)        cs : 23 | slicer | 5 | coop_slicer | 6 | decode | 7 | commit | 8
 	//   kw : 9 | spec | 10 | repair | 11 | fix | 12          aux: 22 | whb_demod | 13 | whb_decode | 14 | whb_commit | 15
+	//   k2 : 24 | fmdev | 25  (only when the discriminator pass runs here)
 	//   t1 : 16 | mark + slicer | 17 | coop_slicer | 18 | decode | 19 | commit | 20
 	auto mark = [&](int k, hipStream_t s_) {
 		if (P.tev)
@@ -2466,6 +2471,12 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	bool t1_waits = false;
 	if (has_tfa2) {
 		TRY(hipStreamWaitEvent(P.k2, P.ev_win, 0));
+		if (P.fmdev_wmax > 0) {
+			mark(24, P.k2);
+			TRY(launch_fmdev(P.k2, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,
+					 n_blocks, P.fmdev_wmax));
+			mark(25, P.k2);
+		}
 		mark(1, P.k2);
 		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
 				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);

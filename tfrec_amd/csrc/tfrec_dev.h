@@ -197,8 +197,13 @@ struct PipeCtl {
 	hipEvent_t ev_k2, ev_kw;   // stage A done
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
 	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
+	// the FM discriminator pass, when it runs at the head of stage A of the TFA_2 family (k2) instead of behind the
+	// front end (its only consumer is that stage): wmax > 0
+	int fmdev_wmax;
+	int16_t *fmdev_out;
+	const uint32_t *prevdec;
 };
-constexpr int kTimingMarks = 24;
+constexpr int kTimingMarks = 26;
 
 constexpr int kNQueues = 8;
 // one more counter after the work queues, with a (stream, slot) list behind the queues' items: the TFA_2-family
