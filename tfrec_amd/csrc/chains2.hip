@@ -218,8 +218,6 @@ __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *_
 			const int n = last - og + 1;
 			if (kind < 2)  // slicer work item: queues 2*kind + {0 long, 1 short}
 				push(2 * kind + (n >= long_window ? 0 : 1), make_uint2((uint32_t)c, (uint32_t)count[a]));
-			if (kind == 2)
-				push(5, make_uint2((uint32_t)c, (uint32_t)count[a]));
 			if (kind == 0 && n >= long_window)  // peak-detector pieces of a long TFA_1 window
 				for (int pc = 0; pc * kMarkSlots * 32 < n; pc++)
 					push(7, make_uint2((uint32_t)c, (uint32_t)count[a] | ((uint32_t)pc << 17)));
@@ -1510,6 +1508,200 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 	}
 }
 
+constexpr int kWhbRunEsc = 0xffff;            // run-length escape: the next two uint16 hold a 32-bit length
+
+// ------------------------------------------------------------------------------------------------ K4'' WHB commit
+// whb_decoder::store_bit (whb.cpp:566-603) over the runs whb_demod_kernel accepted, in two stages like K5:
+//   whb_decode_window  lane per WINDOW, from the decoder registers whb_demod_kernel recorded at the window's first
+//                      bit: replays the runs, collects the rdata bytes the window writes (a 64-bit written-mask:
+//                      before a stream's first flush bytes are also stored without a sync word);
+//   whb_commit_stream  lane per stream: overlays the windows' bytes in order, reports the flushes (whb.cpp:693-697),
+//                      commits the decoder state.
+// Both run in the tail of whb_demod_kernel, by the wave that demodulated the stream (they were kernels of their own:
+// two more launches on the longest chain of the batch, each waiting its turn for the chip).
+__device__ __forceinline__ void whb_store_bit_m(Dec &d, int bit, unsigned long long &wmask)
+{
+	if (bit == d.w_last_bit)
+		d.psk = 1 - d.psk;
+	if (d.psk == d.last_psk)
+		d.nrzs = 1 - d.nrzs;
+	d.w_last_bit = bit;
+	d.last_psk = d.psk;
+	const int out = d.nrzs ^ ((d.lfsr >> 16) & 1) ^ ((d.lfsr >> 11) & 1);
+	d.lfsr = (d.lfsr << 1) | (uint32_t)d.nrzs;
+	d.sr = (d.sr >> 1) | ((uint32_t)out << 31);
+	if (d.sr == 0x2bd42d4bu) {
+		d.synced = 1;
+		d.sr_cnt = 0;
+		d.rdata[0] = d.sr & 0xff;
+		d.rdata[1] = (d.sr >> 8) & 0xff;
+		d.rdata[2] = (d.sr >> 16) & 0xff;
+		d.byte_cnt = 3;
+		wmask |= 7ull;
+	}
+	if (d.sr_cnt == 0) {
+		if (d.byte_cnt < 256) {
+			d.rdata[d.byte_cnt] = (d.sr >> 24) & 0xff;
+			if (d.byte_cnt < 64)
+				wmask |= 1ull << d.byte_cnt;
+		}
+		d.byte_cnt++;
+	}
+	if (d.sr_cnt >= 0)
+		d.sr_cnt = (d.sr_cnt + 1) & 7;
+}
+
+// one lane: window j of stream s
+__device__ __forceinline__ void whb_decode_window(int s, int j, int n_streams, const ChainLaunch &L, int a, const WinTables &T,
+						  uint8_t *__restrict__ my_rdata)
+{
+	{
+		const int c = a * n_streams + s;
+		const ChainState &st = L.states[a][s];
+		const WinResult r = T.result[(size_t)c * T.cap + j];
+		const int og = T.open[(size_t)c * T.cap + j];
+		const uint32_t *ent32 = T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j;
+		unsigned long long wmask = 0;
+		Dec d{ 0u, -1, 0, 0, 0, 0, 0, 0, 0, 0u, 0u, my_rdata };
+		if (j == 0) {  // continues from the carried decoder state
+			const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
+			uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				dst[q] = src[q];
+			d.sr = st.sr;
+			d.sr_cnt = st.sr_cnt;
+			d.byte_cnt = st.byte_cnt;
+			d.synced = st.synced;
+			d.w_last_bit = st.w_last_bit;
+			d.nrzs = st.nrzs;
+			d.lfsr = st.lfsr;
+			wmask = ~0ull;
+		} else {
+			const WhbStart ws = T.whbstart[(size_t)s * T.cap + j];
+			d.sr = ws.sr;
+			d.sr_cnt = ws.sr_cnt;
+			d.byte_cnt = ws.byte_cnt;
+			d.synced = ws.synced;
+			d.lfsr = ws.lfsr;
+			d.nrzs = (int)(ws.lfsr & 1u);
+			d.w_last_bit = d.nrzs ^ ((st.nrzs ^ st.w_last_bit) & 1);  // nrzs(t) = bit(t) ^ K, K fixed per stream
+		}
+		// psk is tracked relative to 0 (store_bit always leaves last_psk == psk; only its parity is carried on)
+		const int nent = r.nbits;
+		int q = 0, widx = -1;
+		uint32_t wcur = 0, wnext = nent > 0 ? ent32[0] : 0u;
+		while (q < nent) {
+			const int wi = q >> 1;
+			if (wi != widx) {
+				wcur = wi == widx + 1 ? wnext : ent32[wi];
+				widx = wi;
+				if (2 * (wi + 1) < nent)
+					wnext = ent32[wi + 1];  // in flight while this word's runs are decoded
+			}
+			int len = (q & 1) ? (int)(wcur >> 16) : (int)(wcur & 0xffff);
+			q++;
+			if (len == kWhbRunEsc) {
+				const uint16_t *e16 = reinterpret_cast<const uint16_t *>(ent32);
+				len = (int)((uint32_t)e16[q] | ((uint32_t)e16[q + 1] << 16));
+				q += 2;
+			}
+			whb_store_bit_m(d, 0, wmask);  // whb.cpp:666-673: one 0, then (len - 1) ones
+			for (int m = 1; m < len; m++)
+				whb_store_bit_m(d, 1, wmask);
+		}
+		if (r.closed)  // the window ends with a flush (whb.cpp:693-697): 16 x store_bit(0) first
+			for (int z = 0; z < 16; z++)
+				whb_store_bit_m(d, 0, wmask);
+		WinDecode &o = T.decode[(size_t)c * T.cap + j];
+		o.sr = d.sr;
+		o.sr_cnt = d.sr_cnt;
+		o.byte_cnt = d.byte_cnt;
+		o.invert = (d.psk ? kWhbFPsk : 0) | (d.synced ? kWhbFSynced : 0) | (d.w_last_bit ? kWhbFLastBit : 0) |
+			   (d.nrzs ? kWhbFNrzs : 0);
+		o.wlen = 0;
+		o.lfsr = d.lfsr;
+		o.wmask = wmask;
+		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(o.vals);
+#pragma unroll
+		for (int q4 = 0; q4 < 4; q4++)
+			dst[q4] = src[q4];
+	}
+}
+
+// one lane: stream s
+__device__ __forceinline__ void whb_commit_stream(int s, int n_streams, int n_blocks, long long sample_base, const ChainLaunch &L,
+						  int a, const WinTables &T, tfrec_amd_event *__restrict__ events,
+						  EventBuf *__restrict__ eb, uint32_t flags, uint8_t *__restrict__ my_rdata)
+{
+	const int M = n_blocks * kBlockDec;
+	const ChainParams &p = L.params[a];
+	ChainState &st = L.states[a][s];
+	const int c = a * n_streams + s;
+	const int count = T.count[c];
+	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
+	{  // rdata[0 .. 64) as the previous submit left them (only these are ever looked at: INTEGRATION.md)
+		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			dst[q] = src[q];
+	}
+	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
+	       my_rdata };
+	for (int j = 0; j < count; j++) {
+		const int close = T.close[(size_t)c * T.cap + j];
+		const int last = close < M ? close : M - 1;
+		const WinResult *rr = &T.result[(size_t)c * T.cap + j];
+		const WinDecode *wd = &T.decode[(size_t)c * T.cap + j];
+		// the window's rdata writes on top of what was there
+		const unsigned long long wm = wd->wmask;
+		const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(wd->vals);
+		uint32_t *vdst = reinterpret_cast<uint32_t *>(my_rdata);
+		if (wm)
+			for (int w = 0; w < 16; w++) {
+				const uint32_t nib = (uint32_t)(wm >> (4 * w)) & 15u;
+				const uint32_t m = ((nib & 1u) ? 0xffu : 0u) | ((nib & 2u) ? 0xff00u : 0u) | ((nib & 4u) ? 0xff0000u : 0u) |
+						   ((nib & 8u) ? 0xff000000u : 0u);
+				vdst[w] = (vdst[w] & ~m) | (vsrc[w] & m);
+			}
+		const int fl = wd->invert;
+		d.sr = wd->sr;
+		d.sr_cnt = wd->sr_cnt;
+		d.byte_cnt = wd->byte_cnt;
+		d.synced = (fl & kWhbFSynced) ? 1 : 0;
+		d.w_last_bit = (fl & kWhbFLastBit) ? 1 : 0;
+		d.nrzs = (fl & kWhbFNrzs) ? 1 : 0;
+		d.psk ^= (fl & kWhbFPsk) ? 1 : 0;
+		d.last_psk = d.psk;
+		d.lfsr = wd->lfsr;
+		if (rr->closed) {  // whb.cpp:693-697
+			const long long rssi =
+				(long long)((unsigned long long)(uint32_t)rr->rssi_i | ((unsigned long long)(uint32_t)rr->offset << 32));
+			flush<2>(e, d, rssi, 0, last);
+		}
+	}
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
+		uint4 *dst = reinterpret_cast<uint4 *>(st.rdata);
+#pragma unroll
+		for (int q2 = 0; q2 < 4; q2++)
+			dst[q2] = src[q2];
+	}
+	st.sr = d.sr;
+	st.sr_cnt = d.sr_cnt;
+	st.byte_cnt = d.byte_cnt;
+	st.synced = d.synced;
+	st.w_last_bit = d.w_last_bit;
+	st.psk = d.psk;
+	st.last_psk = d.last_psk;
+	st.nrzs = d.nrzs;
+	st.lfsr = d.lfsr;
+	st.seq = d.seq;
+}
+
+
 // ------------------------------------------------------------------------------------------------ K4' WHB stage 2
 // whb_demod::demod after the first low-pass (whb.cpp:653-703), wave-cooperative: 32 lanes per stream, two streams
 // per wave.  With only ~1000 streams a lane-per-stream kernel is bound by the issue rate of a lone wave (one
@@ -1532,12 +1724,13 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 // them through whb_decoder::store_bit and reports the flush.  The RSSI sum of a synced interval (:678) is an
 // exact integer, so it is taken as a difference of the power prefix K3a stored per slot.
 constexpr uint32_t kWhbSyncRev = 0xd2b42bd4u;  // bit-reversed 0x2bd42d4b (whb.cpp:582): newest bit at the LSB
-constexpr int kWhbRunEsc = 0xffff;            // run-length escape: the next two uint16 hold a 32-bit length
 
 __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
-						       ChainLaunch L, int a, WinTables T)
+						       long long sample_base, ChainLaunch L, int a, WinTables T,
+						       tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
 {
+	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 256 B, used by the decoder tail
 	__shared__ double2 pb[64];
 	__shared__ double yl[64];
 	constexpr int kStep = 64;  // samples per iteration: one per lane
@@ -1838,204 +2031,15 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		st.rssi_d = rssi_d;
 		st.iir_avg = f;
 	}
-}
-
-// ------------------------------------------------------------------------------------------------ K4'' WHB commit
-// whb_decoder::store_bit (whb.cpp:566-603) over the runs whb_demod_kernel accepted, in two stages like K5:
-//   whb_decode_kernel  lane per WINDOW, from the decoder registers whb_demod_kernel recorded at the window's first
-//                      bit: replays the runs, collects the rdata bytes the window writes (a 64-bit written-mask:
-//                      before a stream's first flush bytes are also stored without a sync word);
-//   whb_commit_kernel  lane per stream: overlays the windows' bytes in order, reports the flushes (whb.cpp:693-697),
-//                      commits the decoder state.
-__device__ __forceinline__ void whb_store_bit_m(Dec &d, int bit, unsigned long long &wmask)
-{
-	if (bit == d.w_last_bit)
-		d.psk = 1 - d.psk;
-	if (d.psk == d.last_psk)
-		d.nrzs = 1 - d.nrzs;
-	d.w_last_bit = bit;
-	d.last_psk = d.psk;
-	const int out = d.nrzs ^ ((d.lfsr >> 16) & 1) ^ ((d.lfsr >> 11) & 1);
-	d.lfsr = (d.lfsr << 1) | (uint32_t)d.nrzs;
-	d.sr = (d.sr >> 1) | ((uint32_t)out << 31);
-	if (d.sr == 0x2bd42d4bu) {
-		d.synced = 1;
-		d.sr_cnt = 0;
-		d.rdata[0] = d.sr & 0xff;
-		d.rdata[1] = (d.sr >> 8) & 0xff;
-		d.rdata[2] = (d.sr >> 16) & 0xff;
-		d.byte_cnt = 3;
-		wmask |= 7ull;
-	}
-	if (d.sr_cnt == 0) {
-		if (d.byte_cnt < 256) {
-			d.rdata[d.byte_cnt] = (d.sr >> 24) & 0xff;
-			if (d.byte_cnt < 64)
-				wmask |= 1ull << d.byte_cnt;
-		}
-		d.byte_cnt++;
-	}
-	if (d.sr_cnt >= 0)
-		d.sr_cnt = (d.sr_cnt + 1) & 7;
-}
-
-__global__ __launch_bounds__(64) void whb_decode_kernel(int n_streams, ChainLaunch L, int a, WinTables T)
-{
-	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
-	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
-	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-	const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
-	const uint32_t count = T.queue[5].count;
-	for (uint32_t idx = tid; idx < count; idx += nthreads) {
-		const uint2 it = T.items[(size_t)5 * total + idx];
-		const int c = (int)it.x, j = (int)it.y;
-		const int s = c - a * n_streams;
-		const ChainState &st = L.states[a][s];
-		const WinResult r = T.result[(size_t)c * T.cap + j];
-		const int og = T.open[(size_t)c * T.cap + j];
-		const uint32_t *ent32 = T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j;
-		unsigned long long wmask = 0;
-		Dec d{ 0u, -1, 0, 0, 0, 0, 0, 0, 0, 0u, 0u, my_rdata };
-		if (j == 0) {  // continues from the carried decoder state
-			const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
-			uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
-#pragma unroll
-			for (int q = 0; q < 4; q++)
-				dst[q] = src[q];
-			d.sr = st.sr;
-			d.sr_cnt = st.sr_cnt;
-			d.byte_cnt = st.byte_cnt;
-			d.synced = st.synced;
-			d.w_last_bit = st.w_last_bit;
-			d.nrzs = st.nrzs;
-			d.lfsr = st.lfsr;
-			wmask = ~0ull;
-		} else {
-			const WhbStart ws = T.whbstart[(size_t)s * T.cap + j];
-			d.sr = ws.sr;
-			d.sr_cnt = ws.sr_cnt;
-			d.byte_cnt = ws.byte_cnt;
-			d.synced = ws.synced;
-			d.lfsr = ws.lfsr;
-			d.nrzs = (int)(ws.lfsr & 1u);
-			d.w_last_bit = d.nrzs ^ ((st.nrzs ^ st.w_last_bit) & 1);  // nrzs(t) = bit(t) ^ K, K fixed per stream
-		}
-		// psk is tracked relative to 0 (store_bit always leaves last_psk == psk; only its parity is carried on)
-		const int nent = r.nbits;
-		int q = 0, widx = -1;
-		uint32_t wcur = 0, wnext = nent > 0 ? ent32[0] : 0u;
-		while (q < nent) {
-			const int wi = q >> 1;
-			if (wi != widx) {
-				wcur = wi == widx + 1 ? wnext : ent32[wi];
-				widx = wi;
-				if (2 * (wi + 1) < nent)
-					wnext = ent32[wi + 1];  // in flight while this word's runs are decoded
-			}
-			int len = (q & 1) ? (int)(wcur >> 16) : (int)(wcur & 0xffff);
-			q++;
-			if (len == kWhbRunEsc) {
-				const uint16_t *e16 = reinterpret_cast<const uint16_t *>(ent32);
-				len = (int)((uint32_t)e16[q] | ((uint32_t)e16[q + 1] << 16));
-				q += 2;
-			}
-			whb_store_bit_m(d, 0, wmask);  // whb.cpp:666-673: one 0, then (len - 1) ones
-			for (int m = 1; m < len; m++)
-				whb_store_bit_m(d, 1, wmask);
-		}
-		if (r.closed)  // the window ends with a flush (whb.cpp:693-697): 16 x store_bit(0) first
-			for (int z = 0; z < 16; z++)
-				whb_store_bit_m(d, 0, wmask);
-		WinDecode &o = T.decode[(size_t)c * T.cap + j];
-		o.sr = d.sr;
-		o.sr_cnt = d.sr_cnt;
-		o.byte_cnt = d.byte_cnt;
-		o.invert = (d.psk ? kWhbFPsk : 0) | (d.synced ? kWhbFSynced : 0) | (d.w_last_bit ? kWhbFLastBit : 0) |
-			   (d.nrzs ? kWhbFNrzs : 0);
-		o.wlen = 0;
-		o.lfsr = d.lfsr;
-		o.wmask = wmask;
-		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
-		uint4 *dst = reinterpret_cast<uint4 *>(o.vals);
-#pragma unroll
-		for (int q4 = 0; q4 < 4; q4++)
-			dst[q4] = src[q4];
-	}
-}
-
-__global__ __launch_bounds__(64) void whb_commit_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
-							int n_blocks, long long sample_base, ChainLaunch L, int a, WinTables T,
-							tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
-{
-	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
-	const int s = blockIdx.x * 64 + threadIdx.x;
-	if (s >= n_streams)
-		return;
-	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
-	const int M = n_blocks * kBlockDec;
-	const ChainParams &p = L.params[a];
-	ChainState &st = L.states[a][s];
-	const int c = a * n_streams + s;
-	const int count = T.count[c];
-	EmitCtx e{ events, eb, flags, (uint32_t)s, L.slot[a], p.sensor_type, sample_base };
-	{  // rdata[0 .. 64) as the previous submit left them (only these are ever looked at: INTEGRATION.md)
-		const uint4 *src = reinterpret_cast<const uint4 *>(st.rdata);
-		uint4 *dst = reinterpret_cast<uint4 *>(my_rdata);
-#pragma unroll
-		for (int q = 0; q < 4; q++)
-			dst[q] = src[q];
-	}
-	Dec d{ st.sr, st.sr_cnt, st.byte_cnt, st.invert, st.synced, st.w_last_bit, st.psk, st.last_psk, st.nrzs, st.lfsr, st.seq,
-	       my_rdata };
-	for (int j = 0; j < count; j++) {
-		const int close = T.close[(size_t)c * T.cap + j];
-		const int last = close < M ? close : M - 1;
-		const WinResult *rr = &T.result[(size_t)c * T.cap + j];
-		const WinDecode *wd = &T.decode[(size_t)c * T.cap + j];
-		// the window's rdata writes on top of what was there
-		const unsigned long long wm = wd->wmask;
-		const uint32_t *vsrc = reinterpret_cast<const uint32_t *>(wd->vals);
-		uint32_t *vdst = reinterpret_cast<uint32_t *>(my_rdata);
-		if (wm)
-			for (int w = 0; w < 16; w++) {
-				const uint32_t nib = (uint32_t)(wm >> (4 * w)) & 15u;
-				const uint32_t m = ((nib & 1u) ? 0xffu : 0u) | ((nib & 2u) ? 0xff00u : 0u) | ((nib & 4u) ? 0xff0000u : 0u) |
-						   ((nib & 8u) ? 0xff000000u : 0u);
-				vdst[w] = (vdst[w] & ~m) | (vsrc[w] & m);
-			}
-		const int fl = wd->invert;
-		d.sr = wd->sr;
-		d.sr_cnt = wd->sr_cnt;
-		d.byte_cnt = wd->byte_cnt;
-		d.synced = (fl & kWhbFSynced) ? 1 : 0;
-		d.w_last_bit = (fl & kWhbFLastBit) ? 1 : 0;
-		d.nrzs = (fl & kWhbFNrzs) ? 1 : 0;
-		d.psk ^= (fl & kWhbFPsk) ? 1 : 0;
-		d.last_psk = d.psk;
-		d.lfsr = wd->lfsr;
-		if (rr->closed) {  // whb.cpp:693-697
-			const long long rssi =
-				(long long)((unsigned long long)(uint32_t)rr->rssi_i | ((unsigned long long)(uint32_t)rr->offset << 32));
-			flush<2>(e, d, rssi, 0, last);
-		}
-	}
-	{
-		const uint4 *src = reinterpret_cast<const uint4 *>(my_rdata);
-		uint4 *dst = reinterpret_cast<uint4 *>(st.rdata);
-#pragma unroll
-		for (int q2 = 0; q2 < 4; q2++)
-			dst[q2] = src[q2];
-	}
-	st.sr = d.sr;
-	st.sr_cnt = d.sr_cnt;
-	st.byte_cnt = d.byte_cnt;
-	st.synced = d.synced;
-	st.w_last_bit = d.w_last_bit;
-	st.psk = d.psk;
-	st.last_psk = d.last_psk;
-	st.nrzs = d.nrzs;
-	st.lfsr = d.lfsr;
-	st.seq = d.seq;
+	// ---- decoder tail: the stream's windows, one per lane, then the stream's commit (lane 0)
+	__threadfence();  // lane 0's runs, results and start registers
+	__syncthreads();
+	for (int j = ln; j < count; j += 64)
+		whb_decode_window(s, j, n_streams, L, a, T, rdata_lds + 256 * ln);
+	__threadfence();
+	__syncthreads();
+	if (ln == 0)
+		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_lds);
 }
 
 // ------------------------------------------------------------------------------------------------ K5
@@ -2361,7 +2365,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// P.tev (optional, kTimingMarks events), one interval per kernel:
 	//   fs : 0 | windows | 21
 	//   k2 : 1 | spec | 2 | repair | 3 | fix | 4(k2)        cs : 23 | slicer | 5 | coop_slicer | 6 | decode | 7 | commit | 8
-	//   kw : 9 | spec | 10 | repair | 11 | fix | 12          aux: 22 | whb_demod | 13 | whb_decode | 14 | whb_commit | 15
+	//   kw : 9 | spec | 10 | repair | 11 | fix | 12          aux: 22 | whb_demod (+ decoder tail) | 13 = 14 = 15
 	//   k2 : 24 | fmdev | 25  (only when the discriminator pass runs here)
 	//   t1 : 16 | mark + slicer | 17 | coop_slicer | 18 | decode | 19 | commit | 20
 	auto mark = [&](int k, hipStream_t s_) {
@@ -2434,14 +2438,12 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 				// launched while the other chains' kernels occupy the chip; without the cap the dispatcher piles its
 				// waves onto the few CUs that happen to have room, where they share SIMDs with each other for their
 				// whole life (measured: 10.4 -> 8.5 ms; above 24 KB the workgroups start to wait for LDS: 12 ms)
-				static const int whb_lds = env_int("TFREC_AMD_WHB_LDS", 22000, 0, 64 << 10);
+				// (the decoder tail of the kernel uses the first 16 KB of it)
+				static const int whb_lds = std::max(64 * 256, env_int("TFREC_AMD_WHB_LDS", 22000, 0, 64 << 10));
 				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
-						   n_blocks, L, a, T);
-				mark(13, P.aux);
-				hipLaunchKernelGGL(whb_decode_kernel, dim3(std::max(1, dec_blocks / 4)), block, 0, P.aux, n_streams, L, a, T);
-				mark(14, P.aux);
-				hipLaunchKernelGGL(whb_commit_kernel, dim3((n_streams + 63) / 64), block, 0, P.aux, dec, dec_stride, n_streams,
 						   n_blocks, sample_base, L, a, T, events, eb, flags);
+				mark(13, P.aux);
+				mark(14, P.aux);
 				mark(15, P.aux);
 			}
 	}

@@ -162,8 +162,8 @@ struct WinTables {
 	MarkPiece *mark;        // [n_streams*slots] indexed by the piece's first slot
 	uint32_t *bits;         // [chains*bit_words] emitted bits, LSB first; window j of a chain starts at word (open>>6)+3*j
 	uint2 *items;           // [8][chains*cap] work items; slicer queues 2*kind + {0: long, 1: short windows}: (chain, j);
-	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment); queue 5: WHB
-	                        // windows (chain, j); queue 7: peak-detector pieces of long TFA_1 windows (chain, j | p << 17)
+	                        // queues 4 (TFA_2 family) and 6 (WHB): biquad segments (chain, segment); queue 5: unused;
+	                        // queue 7: peak-detector pieces of long TFA_1 windows (chain, j | p << 17)
 	WorkQueue *queue;       // [8]
 	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
 	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
