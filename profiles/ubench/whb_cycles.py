@@ -1,0 +1,33 @@
+"""Cycle accounting of whb_demod_kernel (library built with -DTFREC_AMD_PROFILE_WHB, single-wave kernel:
+TFREC_AMD_WHB2=0).  usage: TFREC_AMD_LIB=.../lib_prof.so TFREC_AMD_WHB2=0 python whb_cycles.py [types_hex]"""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+import torch
+from tfrec_amd import synth, api
+mask = int(sys.argv[1], 16) if len(sys.argv) > 1 else 0x20
+ns, nb = 1024, 48
+host = synth.gen_batch(1000, 0, ns, nb)
+d = torch.from_numpy(host).cuda()
+with api.Receiver(ns, mask, 500, 0, max_blocks=nb, max_events=1 << 20) as r:
+    pipelined = len(sys.argv) > 2 and sys.argv[2] == "pipelined"
+    if pipelined:  # three submits in flight, as bench.py runs: the front end of later batches beside this kernel
+        r.submit(d); r.submit(d)
+        for _ in range(6):
+            r.submit(d); r.drain()
+        r.drain(); r.drain()
+        nsub = 8
+    else:
+        nsub = 2
+        for _ in range(2):
+            r.submit(d); r.drain()
+    st = api.Stats()
+    r.L.tfrec_amd_get_stats(r.h, C.byref(st))
+    raw = [int(x) for x in (st.tfa1_recomputed, *st.reserved)]
+    span = [int(st.biquad_unconverged), int(st.biquad_serial), int(st.tfa2_resliced)]
+steps, usteps = raw[0] >> 32, raw[0] & 0xffffffff
+print("per stream and submit: steps %.0f, with recurrence %.0f" % (steps / ns / nsub, usteps / ns / nsub))
+print("cycles per stream and submit: recurrence %.2fM, candidate walk %.2fM, whole demodulator %.2fM" % tuple(x / ns / nsub / 1e6 for x in raw[1:4]))
+print("recurrence: %.0f cycles per step = %.1f per sample" % (raw[1] / max(usteps, 1), raw[1] / max(usteps, 1) / 64))
+if len(sys.argv) > 3 and sys.argv[3] == "span":  # library built with -DTFREC_AMD_PROFILE_WHB_SPAN as well
+    first = (~span[0]) & 0xFFFFFFFFFFFFFFFF
+    print("sixth submit: workgroups start over %.3f ms, kernel first start -> last end %.3f ms" % ((span[1] - first) / 1e5, (span[2] - first) / 1e5))

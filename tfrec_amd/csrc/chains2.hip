@@ -1769,6 +1769,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	int sc = st.sr_cnt, bc = st.byte_cnt;
 	const int count = T.count[c];
 	const bool cont = T.cont[c] != 0;
+#ifdef TFREC_AMD_PROFILE_WHB
+	long long pf_rec = 0, pf_steps = 0, pf_usteps = 0, pf_cand = 0, pf_t0 = __builtin_readcyclecounter();
+	const long long pf_w0 = wall_clock64();  // 100 MHz
+#endif
 
 	auto wave_sum = [&](unsigned long long v) -> unsigned long long {
 #pragma unroll
@@ -1886,7 +1890,27 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
 				__syncthreads();
 				// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association)
+#ifdef TFREC_AMD_PROFILE_WHB
+				const long long pf_a = __builtin_readcyclecounter();
+				pf_usteps++;
+#endif
 				double y1 = f.yn, y2 = f.yn1;
+				// A full step: all feed-forward terms into registers first (the LDS reads are issued back to back, up to
+				// 15 in flight), then the bare chain, fully unrolled -- 47 cycles per sample instead of 76 for the rolled
+				// loop with a read per iteration (cycle counters, profiles/ubench/whb_cycles.py); the chain alone is 29.
+				if (nv == kStep) {
+					double2 v[kStep];
+#pragma unroll
+					for (int k = 0; k < kStep; k++)
+						v[k] = pb[k];
+#pragma unroll
+					for (int k = 0; k < kStep; k++) {
+						const double y = ((v[k].y + cavg.a1 * y1) + v[k].x) + cavg.a2 * y2;
+						yl[k] = y;
+						y2 = y1;
+						y1 = y;
+					}
+				} else
 #pragma unroll 4
 				for (int k = 0; k < nv; k++) {
 					const double2 v = pb[k];
@@ -1896,6 +1920,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					y1 = y;
 				}
 				__syncthreads();
+#ifdef TFREC_AMD_PROFILE_WHB
+				pf_rec += __builtin_readcyclecounter() - pf_a;
+#endif
 				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
 				avgn = (int)yl[ln];
 			}
@@ -1906,6 +1933,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			bool locked_here = false;
 			int rssi_from = synced ? 0 : kStep;  // first sample of the step that counts for the rssi
 			// ---- (4) accepted candidates
+#ifdef TFREC_AMD_PROFILE_WHB
+			const long long pf_c = __builtin_readcyclecounter();
+			pf_steps++;
+#endif
 			while (mask) {
 				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
 				if (kmin > kStep - 1)
@@ -1957,6 +1988,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					locked_here = true;
 				}
 			}
+#ifdef TFREC_AMD_PROFILE_WHB
+			pf_cand += __builtin_readcyclecounter() - pf_c;
+#endif
 			const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
 			const int dl2 = nv > 1 ? __builtin_amdgcn_readlane(dev, nv > 1 ? nv - 2 : 0) : pd1;
 			if (unsynced0 && !locked_here) {  // the whole step went through the average
@@ -2031,6 +2065,21 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		st.rssi_d = rssi_d;
 		st.iir_avg = f;
 	}
+#ifdef TFREC_AMD_PROFILE_WHB
+	if (ln == 0) {  // cycles: recurrence | candidate walk | whole demodulator; steps: all | with the recurrence
+		atomicAdd(&T.stats[5], (unsigned long long)pf_rec);
+		atomicAdd(&T.stats[6], (unsigned long long)pf_cand);
+		atomicAdd(&T.stats[7], (unsigned long long)(__builtin_readcyclecounter() - pf_t0));
+		atomicAdd(&T.stats[4], (unsigned long long)((pf_steps << 32) | pf_usteps));
+#ifdef TFREC_AMD_PROFILE_WHB_SPAN  // of the sixth submit: earliest / latest workgroup start, latest end (100 MHz ticks)
+		if (sample_base == 5LL * n_blocks * kBlockDec) {
+			atomicMax(&T.stats[1], ~(unsigned long long)pf_w0);
+			atomicMax(&T.stats[2], (unsigned long long)pf_w0);
+			atomicMax(&T.stats[3], (unsigned long long)wall_clock64());
+		}
+#endif
+	}
+#endif
 	// ---- decoder tail: the stream's windows, one per lane, then the stream's commit (lane 0)
 	__threadfence();  // lane 0's runs, results and start registers
 	__syncthreads();
