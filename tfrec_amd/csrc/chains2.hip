@@ -2441,7 +2441,10 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// biquad segments: at most (M/32 + windows)/kSegSlots + 1 per chain
 	const int seg_blocks = std::min(16384, (int)(((size_t)L.n_active * n_streams * ((size_t)n_blocks * (kBlockDec / 32) / kSegSlots + 4) +
 						       lanes_win - 1) / lanes_win));
-	static const int long_window = env_int("TFREC_AMD_COOP_MIN", kLongWindow, 356);
+	// (few chains: the lanes of the lane-per-window kernels are mostly idle anyway and latency is all that counts)
+	static const int long_window_env = env_int("TFREC_AMD_COOP_MIN", 0, 0);
+	const int long_window = long_window_env >= 356 ? long_window_env
+						       : ((size_t)n_streams * L.n_active >= 1024 ? kLongWindow : kLongWindow / 2);
 	// long windows: at most M / long_window per chain
 	const int coop_blocks = std::min(env_int("TFREC_AMD_COOP_BLOCKS", 32768, 1, 1 << 20), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
 								((size_t)n_blocks * kBlockDec / (size_t)std::max(long_window, 356) + 1), 1u << 30)));
@@ -2483,12 +2486,12 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		mark(22, P.aux);
 		for (int a = 0; a < L.n_active; a++)
 			if (L.params[a].kind == 2) {
-				// 22 KB of dynamic LDS nobody uses: at most 7 of this kernel's one-wave workgroups fit on a CU.  It is
-				// launched while the other chains' kernels occupy the chip; without the cap the dispatcher piles its
-				// waves onto the few CUs that happen to have room, where they share SIMDs with each other for their
-				// whole life (measured: 10.4 -> 8.5 ms; above 24 KB the workgroups start to wait for LDS: 12 ms)
-				// (the decoder tail of the kernel uses the first 16 KB of it)
-				static const int whb_lds = std::max(64 * 256, env_int("TFREC_AMD_WHB_LDS", 22000, 0, 64 << 10));
+				// 16 KB of dynamic LDS (the decoder tail of the kernel uses it): at most 9 of this kernel's one-wave workgroups
+				// fit on a CU.  It is launched while the other chains' kernels occupy the chip; without a cap the dispatcher
+				// piled its waves onto the few CUs that happened to have room, where they shared SIMDs with each other for
+				// their whole life (10.4 -> 8.5 ms when the cap was introduced, then 22 KB = 7 per CU; with the deep layout
+				// 16 KB measures 3 % better than 22 KB, and 30 KB 8 % worse).  TFREC_AMD_WHB_LDS raises it.
+				static const int whb_lds = std::max(64 * 256, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
 				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
 						   n_blocks, sample_base, L, a, T, events, eb, flags);
 				mark(13, P.aux);
@@ -2497,7 +2500,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			}
 	}
 	TRY(hipEventRecord(P.done[1], P.aux));
-	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 48));
+	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 64));
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
 		if (kind == 0)
