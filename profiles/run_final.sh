@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -- python $R/bench.py --cpu-b
 for f in /tmp/prof_$tag/*/*.db; do
 	python $R/profiles/rocpd_summary.py $f > $R/gpurun_out/${tag}_kernel_stats.txt
 	python $R/profiles/rocpd_timeline.py $f > $R/gpurun_out/${tag}_timeline.txt
+	python $R/profiles/rocpd_steps.py $f > $R/gpurun_out/${tag}_steps.txt   # two steady-state batches, with stream ids
 done
 cat $R/gpurun_out/${tag}_kernel_stats.txt
 # PMC passes (counters only: no trace domains)

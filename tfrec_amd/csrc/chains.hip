@@ -25,6 +25,8 @@
 
 namespace tfrec {
 
+__device__ __constant__ double kAtanPolySerial[11] = TFREC_ATAN_POLY;  // see dsp_dev.h
+
 template <int KIND>
 __device__ __forceinline__ void chain_body(const uint32_t *__restrict__ dec, size_t dec_stride,
 					   const unsigned long long *__restrict__ mask, size_t mask_stride, int n_streams,
@@ -141,7 +143,7 @@ __device__ __forceinline__ void chain_body(const uint32_t *__restrict__ dec, siz
 				timeout_cnt = p.window;
 			}
 			bool unc;
-			const int dev0 = fm_dev(I, Q, pI, pQ, &unc);
+			const int dev0 = fm_dev(I, Q, pI, pQ, &unc, kAtanPolySerial);
 			if (unc)
 				atomicAdd(&eb->uncertain, 1ull);
 			const int ld = d2i(iir_step(iir, p.iir, (double)dev0));

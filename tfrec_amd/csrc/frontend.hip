@@ -24,6 +24,8 @@
 
 namespace tfrec {
 
+__device__ __constant__ double kAtanPolyFront[11] = TFREC_ATAN_POLY;  // see dsp_dev.h
+
 // first-stage taps (dsp_stuff.cpp:119-130)
 __device__ __constant__ const int kS1[8] = { 2443, 6339, 11036, 14254, 14254, 11036, 6339, 2443 };
 
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 	for (int o = 0; o < 4; o++) {
 		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
 		bool unc;
-		dv[o] = fm_dev(I, Q, pI, pQ, &unc);
+		dv[o] = fm_dev(I, Q, pI, pQ, &unc, kAtanPolyFront);
 		n_unc += unc ? 1u : 0u;
 		pI = I;
 		pQ = Q;
