@@ -99,7 +99,7 @@ typedef struct {
 	/* individual kernels of the window-parallel pipeline (0 when not run).  Window scan, then the TFA_2-family chain: */
 	float windows_ms, spec_biquad_ms, repair_biquad_ms, fix_biquad_ms, slicer_ms, coop_slicer_ms, decode_ms, commit_ms;
 	/* the WHB chain runs beside them on its own stream: its three biquad kernels together, then stage 2 */
-	float whb_biquad_ms, whb_demod_ms, whb_decode_ms, whb_commit_ms;
+	float whb_biquad_ms, whb_demod_ms, whb_decode_ms, whb_commit_ms; /* decode / commit: 0 (part of whb_demod) */
 	/* ... and so does the TFA_1 chain (no biquad stage): short-window slicer, cooperative slicer, decode + commit */
 	float tfa1_slicer_ms, tfa1_coop_slicer_ms, tfa1_decode_commit_ms;
 	float fmdev_ms;    /* FM discriminator pass of the front end (tiles near trigger windows) */

@@ -877,8 +877,7 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	if (has[1]) {
 		HIPCHK(hipEventElapsedTime(&out->whb_biquad_ms, tev[9], tev[12]));
 		HIPCHK(hipEventElapsedTime(&out->whb_demod_ms, tev[22], tev[13]));
-		HIPCHK(hipEventElapsedTime(&out->whb_decode_ms, tev[13], tev[14]));
-		HIPCHK(hipEventElapsedTime(&out->whb_commit_ms, tev[14], tev[15]));
+		// whb_decode_ms / whb_commit_ms stay 0: those stages run in the tail of whb_demod_kernel
 	}
 	return TFREC_AMD_OK;
 }

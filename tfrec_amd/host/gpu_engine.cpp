@@ -108,7 +108,8 @@ void gpu_engine::replay(const tfrec_amd_event &ev)
 //   reader thread : fread batch k+2 of every file into a pinned host buffer (three buffers in rotation)
 //   GPU           : H2D copy + hot path of batch k+1 (tfrec_amd_submit_host is asynchronous on pinned memory)
 //   this thread   : drain batch k's flush events and replay them into the decoders
-// The C ABI's submit/drain FIFO of depth two is what lets batch k+1 be queued before batch k is drained.
+// The C ABI's submit/drain FIFO (depth TFREC_AMD_FIFO_DEPTH = 3) is what lets batch k+1 be queued before batch k is
+// drained; this loop keeps two in flight (the host side, not the GPU, bounds a file replay: DESIGN.md section 6).
 int gpu_engine::run()
 {
 	const size_t n = files.size();
