@@ -332,6 +332,19 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			p.spb = (1536000 / 4.0) / reg[s].baud;
 			if (p.kind == 1) {
 				p.window = d2i_host(16 * p.spb);  // tfa2.cpp:355
+				// multiplier form of numbits (ChainParams::nb_mul), accepted only if it reproduces the fp64 expression
+				// for every argument the slicer can form
+				const int hmax = (int)(16 * p.spb) + 2;
+				const uint64_t a0 = (uint64_t)((double)(1ull << 40) / p.spb);
+				for (uint64_t a_try : { a0, a0 + 1, a0 - 1 }) {
+					bool ok = true;
+					for (int h = 0; h <= hmax && ok; h++)
+						ok = tfa2_numbits_mul(2 * h, a_try) == (int)(((double)h + p.spb / 2) / p.spb);
+					if (ok) {
+						p.nb_mul = a_try;
+						break;
+					}
+				}
 				p.iir = biquad_coef(0.5 / p.spb);  // tfa2.cpp:321
 			} else {
 				p.window = d2i_host(8 * p.spb);         // whb.cpp:641

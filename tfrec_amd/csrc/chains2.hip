@@ -815,7 +815,8 @@ __device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int g, int
 }
 
 // One sample of tfa2_demod::demod inside a window (tfa2.cpp:357-412), ld = (int)iir->step(fm_dev(...)).
-__device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int ld, const uint32_t *drow, double spb)
+__device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int ld, const uint32_t *drow, double spb,
+					    uint64_t nb_mul)
 {
 	const int b = g >> 13;
 	if (b != f.cur_block) {
@@ -846,7 +847,7 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 			f.bitcnt++;
 			const int tdiff = index - f.lbi;
 			if (tdiff > spb / 4 && tdiff < 32 * spb) {
-				const int numbits = d2i(((tdiff / 2) + (spb / 2)) / spb);
+				const int numbits = nb_mul ? tfa2_numbits_mul(tdiff, nb_mul) : d2i(((tdiff / 2) + (spb / 2)) / spb);
 				if (numbits < 32)
 					for (int n = 1; n < numbits; n++)
 						bw.put(f.last_bit);
@@ -878,7 +879,7 @@ struct Slot4 {
 template <int KIND>
 __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int last, bool closed,
 					  const uint32_t *__restrict__ drow, const uint32_t *__restrict__ ldslots, int prevI,
-					  int prevQ, double spb, uint4 *__restrict__ my_lds, int head_chunks)
+					  int prevQ, double spb, uint64_t nb_mul, uint4 *__restrict__ my_lds, int head_chunks)
 {
 	const int n = last - g0 + 1;
 	const int nch = (n + kChunk - 1) >> 5;
@@ -950,7 +951,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 				for (int t = 0; t < 8; t++) {
 					if (8 * q + t < nv) {
 						const int ld = (int)(int16_t)((vw[t >> 1] >> (16 * (t & 1))) & 0xffff);
-						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, drow, spb);
+						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, drow, spb, nb_mul);
 					}
 				}
 			}
@@ -1011,7 +1012,7 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
 							(size_t)win_slot0(og, j) * 16
 					      : nullptr;
-	const int resume = run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, my_lds,
+	const int resume = run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, p.nb_mul, my_lds,
 					    head_chunks);
 	bw.finish();
 	WinResult &r = T.result[(size_t)c * T.cap + j];
@@ -1186,6 +1187,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	const int lane = threadIdx.x;
 	const int a = c / n_streams, s = c - a * n_streams;
 	const double spb = L.params[a].spb;
+	const uint64_t nb_mul = L.params[a].nb_mul;
 	const int og = T.open[(size_t)c * T.cap + j];
 	const int close = T.close[(size_t)c * T.cap + j];
 	const bool closed = close < M;
@@ -1241,7 +1243,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 			bitcnt++;
 			const int tdiff = index - lbi;
 			if (tdiff >= td_lo && tdiff <= td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
-				const int numbits = d2i(((tdiff / 2) + (spb / 2)) / spb);
+				const int numbits = nb_mul ? tfa2_numbits_mul(tdiff, nb_mul) : d2i(((tdiff / 2) + (spb / 2)) / spb);
 				if (numbits < 32)
 					bw.put_run(last_bit, numbits - 1);
 				bw.put_run(bit, 1);

@@ -67,7 +67,16 @@ struct ChainParams {
 	int32_t min_bytes;   // smallest byte_cnt a flush can turn into a telegram
 	double spb;
 	BiquadCoef iir, iir_avg;
+	// tfa2.cpp:397 numbits = (int)(((tdiff / 2) + spb / 2) / spb) without the fp64 division: for every h = tdiff / 2 the
+	// slicer can pass (tdiff < 32 * spb) it equals (h * nb_mul + 2^39) >> 40 -- checked exhaustively against the fp64
+	// expression when the context is created; 0 = no multiplier passed the check, the kernels divide.
+	uint64_t nb_mul;
 };
+
+__host__ __device__ inline int tfa2_numbits_mul(int tdiff, uint64_t nb_mul)
+{
+	return (int)(((uint64_t)(uint32_t)(tdiff >> 1) * nb_mul + (1ull << 39)) >> 40);
+}
 
 // everything one chains launch needs, passed by value as kernel argument
 struct ChainLaunch {
