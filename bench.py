@@ -100,7 +100,7 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
     try:
         ncpu = usable_cores()
         a_ = np.ascontiguousarray(iq_sample)
-        n_jobs = max(64, 8 * ncpu)
+        n_jobs = max(256, 32 * ncpu)  # about a second of work on every thread
         dt = O.lib().orc_time_many(types, thresh, 0, a_.ctypes.data, a_.strides[0], a_.shape[1], n_streams, n_jobs, ncpu)
         res["all_cores"] = dict(value=round(n_jobs * samples_per_stream / dt / 1e6, 1), unit="MSamples/s", cores=ncpu,
                                 kind="port", sample="%d streams x %d blocks, one receiver per stream, %d threads (of %d "
@@ -121,7 +121,8 @@ def main():
     ap.add_argument("--types", type=lambda x: int(x, 16), default=0x2F)
     ap.add_argument("--thresh", type=int, default=500)
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic streams to generate per GPU (0 = auto)")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=12.0,
+                    help="upper bound in seconds for each single-thread leg of the CPU baseline (0 = skip)")
     ap.add_argument("--parity-streams", type=int, default=4)
     ap.add_argument("--depth", type=int, default=3, help="batches kept in the submit/drain FIFO (1..3)")
     ap.add_argument("--input-10x", action="store_true",
@@ -284,7 +285,7 @@ def main():
             },
         }
         if a.cpu_budget > 0 and world == 1 and rate == 1:
-            out["cpu_baseline"] = cpu_baseline(host[: min(unique, 64)], a.types, a.thresh, a.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(host[: min(unique, 256)], a.types, a.thresh, a.cpu_budget)
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:
