@@ -75,6 +75,7 @@ struct tfrec_amd_ctx {
 	// four streams, whatever GPU_MAX_HW_QUEUES is.
 	hipStream_t cp = nullptr;
 	bool deep = false;
+	bool scan_on_kw = false;                      // deep layout: the window scan runs at the head of kw, not on fs
 	bool fmdev_k2 = false;                        // the discriminator pass runs at the head of k2, not behind the front end
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
 	hipEvent_t ev_pipe[kSets][4] = {};                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
@@ -526,6 +527,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		bool has_whb = false;
 		for (int a = 0; a < c->launch.n_active; a++)
 			has_whb = has_whb || c->launch.params[a].kind == 2;
+		c->scan_on_kw = getenv("TFREC_AMD_SCAN_KW") ? atoi(getenv("TFREC_AMD_SCAN_KW")) != 0 : true;
 		c->fmdev_k2 = getenv("TFREC_AMD_FMDEV_K2") ? atoi(getenv("TFREC_AMD_FMDEV_K2")) != 0 : has_whb;
 		c->k2 = c->cs;
 		c->kw = c->aux;
@@ -606,8 +608,8 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][1], fs));
+	HIPCHK(hipEventRecord(c->ev_front[set], fs));
 	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) {
-		HIPCHK(hipEventRecord(c->ev_front[set], fs));
 		HIPCHK(hipStreamWaitEvent(st, c->ev_front[set], 0));
 		HIPCHK(launch_chains(st, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->cfg.n_streams, n_blocks,
 				     c->sample_base, c->launch, c->d_events[set], c->d_eb[set], c->cfg.flags));
@@ -618,6 +620,8 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	} else {
 		PipeCtl P;
 		P.fs = fs;
+		P.ws = (c->deep && c->scan_on_kw) ? c->kw : fs;
+		P.ev_front = c->ev_front[set];
 		P.k2 = c->k2;
 		P.kw = c->kw;
 		P.cs = c->cs;

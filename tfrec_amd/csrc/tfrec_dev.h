@@ -198,7 +198,9 @@ struct WinTables {
 // submits use different table / buffer sets.  k2 == cs and kw == aux is allowed (shallow layout: with the HIP
 // default of 4 hardware queues more streams would share queues and serialise).
 struct PipeCtl {
-	hipStream_t fs;            // front-end stream: the window scan is appended to it
+	hipStream_t fs;            // front-end stream
+	hipStream_t ws;            // stream of the window scan: fs, or (deep layout) kw, after ev_front
+	hipEvent_t ev_front;       // front end done (fs)
 	hipStream_t k2, kw;        // stage A: biquads of the TFA_2 family / of WHB
 	hipStream_t cs, aux, t1;   // stage B: TFA_2 family, WHB, TFA_1 (no stage A)
 	hipEvent_t ev_win;         // window scan done (fs)
