@@ -106,24 +106,26 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		} else {
 #pragma unroll
 			for (int i = 0; i < 7; i++) {
-				const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement (u8 - 128); kept as d << 15
-				di[2 * i] = (int)(w << 24) >> 9;
-				dq[2 * i] = (int)((w << 16) & 0xff000000u) >> 9;
-				di[2 * i + 1] = (int)((w << 8) & 0xff000000u) >> 9;
-				dq[2 * i + 1] = (int)(w & 0xff000000u) >> 9;
+				// bytes become two's complement (u8 - 128); each is moved to bits 16..23 of a word of its own, i.e.
+				// d << 16 as the 24-bit operand of v_mul_hi_i32_i24 (bit 23 is the sign): one v_perm_b32 per sample
+				const uint32_t w = rp[i] ^ 0x80808080u;
+				di[2 * i] = (int)__builtin_amdgcn_perm(0u, w, 0x0c000c0cu);
+				dq[2 * i] = (int)__builtin_amdgcn_perm(0u, w, 0x0c010c0cu);
+				di[2 * i + 1] = (int)__builtin_amdgcn_perm(0u, w, 0x0c020c0cu);
+				dq[2 * i + 1] = (int)__builtin_amdgcn_perm(0u, w, 0x0c030c0cu);
 			}
 		}
 		int oi[4], oq[4];
 #pragma unroll
 		for (int o = 0; o < 4; o++) {
 			// (d*h) >> 10 for d = u8-128, (x*h) >> 16 for int16 x: both as the high word of a 24x24-bit product of
-			// pre-shifted operands (d<<15 and h<<7: 23 and 21 bits; x<<8 and h<<8: 24 and 22 bits) -- one full-rate
+			// pre-shifted operands (d<<16 and h<<6: 24 and 20 bits; x<<8 and h<<8: 24 and 22 bits) -- one full-rate
 			// multiply per tap instead of multiply + shift
 			int si = 0, sq = 0;
 #pragma unroll
 			for (int n = 0; n < 8; n++) {
-				si += mulhi24(kS1[n] << (IN16 ? 8 : 7), di[2 * o + n]);
-				sq += mulhi24(kS1[n] << (IN16 ? 8 : 7), dq[2 * o + n]);
+				si += mulhi24(kS1[n] << (IN16 ? 8 : 6), di[2 * o + n]);
+				sq += mulhi24(kS1[n] << (IN16 ? 8 : 6), dq[2 * o + n]);
 			}
 			oi[o] = (int)(int16_t)si << 8;
 			oq[o] = (int)(int16_t)sq << 8;
