@@ -4,27 +4,32 @@
 // the plugins, fm_demod.cpp:34-56, tfa1.cpp:143-190, tfa2.cpp:346-442, whb.cpp:632-707), re-cut so that
 // only what the reference really serialises stays serial:
 //
-//   K2 windows_kernel   lane per (stream, slot): max-scan over the trigger mask -> list of trigger windows
-//                       (tfa1.cpp:147-149,179 / tfa2.cpp:351-355,428 / whb.cpp:636-641,691: a window opens at a
-//                       pwr>thresh sample while the counter is 0 and its flush fires W-1 samples after the
-//                       last trigger).
-//   K3 biquad_kernel    lane per (stream, slot): the fp64 biquads (iir2::step) are the one recurrence whose
-//                       state crosses windows; this pass does nothing else: 8 samples per 16-byte load,
-//                       TFA_2/TFA_3/TX22 read the shared fm_dev array of the front-end, WHB computes
-//                       fm_dev_nrzs on the fly; outputs are the truncated integers the slicers consume.
-//   K4 slicer_kernel    lane per WINDOW (work queue, long windows first): the bit slicers of TFA_1 and the
-//                       TFA_2 family are window-local state machines (state reset at window open/close) --
-//                       except tfa2's last_bit_idx, which is never reset (tfa2.cpp:325-334).  It can only
-//                       influence a window through its first candidate edge, so windows are run assuming a
-//                       far-away last edge and the assumption is checked (and the window re-run exactly) in K5.
-//                       Output: the bits handed to decoder::store_bit, packed.
-//   K4' whb_demod_kernel  wave per stream: WHB stage 2 (decision-level biquad, phase-change detector); the
-//                       demodulator needs the decoder's has_sync() (whb.cpp:653, 677, 693), which is tracked
-//                       with a lane-parallel evaluation of the (GF(2)-linear) sync search.  Output: bit runs.
-//   K4'' whb_commit_kernel lane per stream: whb_decoder::store_bit over the runs, flush events.
-//   K5 commit_kernel    lane per (stream, slot): walks the windows in order: validates/repairs the tfa2
-//                       speculation, runs the decoders (store_bit / flush) over the packed bits with their
-//                       persistent state (sr, rdata), emits events, commits ChainState for the next submit.
+//   K2  windows_kernel     wave per stream: scan over the trigger mask -> per (stream, slot) the list of trigger
+//                          windows (tfa1.cpp:147-149,179 / tfa2.cpp:351-355,428 / whb.cpp:636-641,691: a window opens
+//                          at a pwr>thresh sample while the counter is 0 and its flush fires W-1 samples after the
+//                          last trigger), virtual slot numbering, work queues.
+//   K3  spec_biquad_kernel (speculate, repair, second repair) + fix_biquad_kernel (verify): the fp64 biquads
+//                          (iir2::step) are the one recurrence whose state crosses windows.  TFA_2/TFA_3/TX22 read
+//                          the fm_dev array of fmdev_kernel, WHB computes fm_dev_nrzs on the fly; outputs are the
+//                          truncated integers the slicers consume.  Lane per 4096-sample segment (see K3 below).
+//   K4  slicer_kernel      lane per WINDOW (work queue, long windows first): the bit slicers of TFA_1 and the
+//                          TFA_2 family are window-local state machines (state reset at window open/close) --
+//                          except tfa2's last_bit_idx, which is never reset (tfa2.cpp:325-334).  It can only
+//                          influence a window through its first candidate edge, so windows are run assuming a
+//                          far-away last edge and the assumption is checked (and the window re-run exactly) in K5.
+//                          Output: the bits handed to decoder::store_bit, packed.
+//   K4a mark_kernel, K4b coop_slicer_kernel: windows of 4096 samples and more: wave per window (see K4b below).
+//   K4' whb_demod_kernel   wave per stream: WHB stage 2 (decision-level biquad, phase-change detector); the
+//                          demodulator needs the decoder's has_sync() (whb.cpp:653, 677, 693), which is tracked
+//                          with a lane-parallel evaluation of the (GF(2)-linear) sync search.  Output: bit runs.
+//                          In its tail (K4''): whb_decoder::store_bit over the runs, lane per window, then the
+//                          stream's flush events and decoder state.
+//   K5  decode_kernel      lane per window: the decoders (store_bit) over the window's packed bits;
+//       commit_kernel      lane per (stream, slot): walks the windows in order: checks the tfa2 speculation (a chain
+//                          with a window to re-run goes to commit_wave_kernel, wave per chain), overlays the windows'
+//                          rdata bytes, emits the flush events, commits ChainState for the next submit.
+// launch_pipeline (end of file) puts them on six streams: the stages of three consecutive submits run beside each
+// other.
 #include <stdlib.h>
 
 #include <algorithm>
