@@ -15,3 +15,25 @@ def test_tfa2_numbits_multiplier_reproduces_the_fp64_expression():
                 found = a
                 break
         assert found is not None, baud
+
+
+def test_python_constants_match_the_c_header():
+    """The ctypes binding restates a few constants of include/tfrec_amd.h; they must not drift."""
+    import os
+    import re
+
+    from tfrec_amd import api
+
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "tfrec_amd.h")).read()
+
+    def define(name):
+        m = re.search(r"#define\s+%s\s+([0-9xa-fA-Fu]+)" % name, hdr)
+        assert m, name
+        return int(m.group(1).rstrip("u"), 0)
+
+    assert define("TFREC_AMD_FIFO_DEPTH") == api.FIFO_DEPTH
+    assert define("TFREC_AMD_BLOCK_BYTES") == api.BLOCK_BYTES
+    assert define("TFREC_AMD_BLOCK_DEC") == api.BLOCK_DEC
+    assert define("TFREC_AMD_NSLOTS") == api.NSLOTS
+    for flag in ("ALL_FLUSHES", "TIMING", "SERIAL_CHAINS", "INPUT_10X"):
+        assert define("TFREC_AMD_F_" + flag) == getattr(api, "F_" + flag)
