@@ -189,30 +189,30 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 
 // ---- FM discriminator (fm_dev, dsp_stuff.cpp:284-292) of every decimated sample against its predecessor.  The fp64
 // atan2 is a pure map, so it runs here in parallel instead of inside the serial demodulator chains; TFA_2, TFA_3 and
-// TX22 (tfa2.cpp:361) all consume this one array.  Only samples inside a trigger window are ever read: a tile of
-// 1024 samples is computed iff a trigger lies in it or within `wmax` samples before it (wmax = the longest window of
-// the registered demodulators; the first tile always, a window may be open from the previous submit) -- about half
-// of the tiles in the benchmark workload.  Same 256 x 4 lane layout as the front end.
+// TX22 (tfa2.cpp:361) all consume this one array.  Only samples inside a trigger window are ever read: a piece of
+// 256 samples (one wave) is computed iff a trigger lies in it or within `wmax` samples before it (wmax = the longest
+// window of the registered demodulators; the first wmax samples always, a window may be open from the previous
+// submit) -- about half of the benchmark workload.  Same 256 x 4 lane layout as the front end.
 __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							      const unsigned long long *__restrict__ mask, size_t mask_stride,
 							      const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
 							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax)
 {
-	__shared__ int any;
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	if (tile > 0 && wmax < kTileDec) {
-		if (tid == 0)
-			any = 0;
-		__syncthreads();
-		const int w0 = (m0 - wmax) >> 6, w1 = (m0 + kTileDec - 1) >> 6;  // m0 >= 1024 > wmax
-		const int w = w0 + tid;
-		if (w <= w1 && mask[(size_t)s * mask_stride + w] != 0ull)
-			any = 1;
-		__syncthreads();
-		if (!any)
-			return;
+	// A sample is read by a demodulator only inside a trigger window, i.e. if a trigger lies at most wmax - 1 samples
+	// before it (the first wmax samples of a submit may belong to a window left open by the previous one).  Decided
+	// per wave = per 256 samples: the mask words of [first - wmax, last], one per lane, one ballot.
+	{
+		const int mw = m0 + 4 * (tid & ~63);  // the wave's first sample
+		if (mw >= wmax) {
+			const int w0 = (mw - wmax) >> 6, w1 = (mw + 255) >> 6;
+			const int w = w0 + (tid & 63);
+			const bool hit = w <= w1 && mask[(size_t)s * mask_stride + w] != 0ull;
+			if (__ballot(hit) == 0ull)
+				return;
+		}
 	}
 	const uint4 v = *reinterpret_cast<const uint4 *>(drow + m0 + 4 * tid);
 	const uint32_t pw = (m0 + 4 * tid) > 0 ? drow[m0 + 4 * tid - 1] : prevdec[s];
