@@ -69,6 +69,8 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const int tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
 	const long nbytes = 8L * kB * m_total;
+	if (!IN16)  // MODE.FP_ROUND (fp32) = 2, round toward -inf: see stage 1.  The kernel has no other fp32 arithmetic.
+		__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);
 	const uint8_t *src = iq + (size_t)s * stride;
 
 	// ---- stage raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) into LDS, 16 B per lane, coalesced
@@ -96,39 +98,56 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	constexpr int kGroups = (2 * kTileDec + 24 + 3) / 4;
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
 		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + kB * (12 + 16 * grp));
-		int di[14], dq[14];
+		int oi[4], oq[4];
 		if (IN16) {
+			int di[14], dq[14];
 #pragma unroll
 			for (int i = 0; i < 14; i++) {  // x << 8
 				di[i] = (int)(int16_t)(rp[i] & 0xffff) << 8;
 				dq[i] = ((int)rp[i] >> 16) << 8;
 			}
+#pragma unroll
+			for (int o = 0; o < 4; o++) {
+				// (x*h) >> 16 as the high word of the 24x24-bit product of x<<8 and h<<8 (24 and 22 bits): one full-rate
+				// multiply per tap instead of multiply + shift
+				int si = 0, sq = 0;
+#pragma unroll
+				for (int n = 0; n < 8; n++) {
+					si += mulhi24(kS1[n] << 8, di[2 * o + n]);
+					sq += mulhi24(kS1[n] << 8, dq[2 * o + n]);
+				}
+				oi[o] = (int)(int16_t)si << 8;
+				oq[o] = (int)(int16_t)sq << 8;
+			}
 		} else {
+			// u8 input: d = u8 - 128 has 8 bits and h 14, so d * (h / 1024) is exact in fp32, and with the wave's fp32
+			// rounding mode set to "toward -inf" (top of the kernel)
+			//     acc = fma(d, h / 1024, acc),  acc an integer in [2^23, 2^24)  (one ulp = 1)
+			// adds exactly floor(d * h / 1024) = (d * h) >> 10 to acc: the per-tap arithmetic shift of the reference in
+			// ONE instruction per tap -- and v_pk_fma_f32 does the I and the Q rail at once.  (The integer form costs a
+			// multiply and an add per tap and rail.)  The 8 taps sum to at most 8 * 1782, so acc stays in range and the
+			// int16 store of the reference (dsp_stuff.cpp:222) changes nothing.
+			typedef float f32x2 __attribute__((ext_vector_type(2)));
+			f32x2 d[14];
 #pragma unroll
 			for (int i = 0; i < 7; i++) {
-				// bytes become two's complement (u8 - 128); each is moved to bits 16..23 of a word of its own, i.e.
-				// d << 16 as the 24-bit operand of v_mul_hi_i32_i24 (bit 23 is the sign): one v_perm_b32 per sample
-				const uint32_t w = rp[i] ^ 0x80808080u;
-				di[2 * i] = (int)__builtin_amdgcn_perm(0u, w, 0x0c000c0cu);
-				dq[2 * i] = (int)__builtin_amdgcn_perm(0u, w, 0x0c010c0cu);
-				di[2 * i + 1] = (int)__builtin_amdgcn_perm(0u, w, 0x0c020c0cu);
-				dq[2 * i + 1] = (int)__builtin_amdgcn_perm(0u, w, 0x0c030c0cu);
+				const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement: one signed byte conversion each
+				d[2 * i] = f32x2{ (float)(signed char)(w), (float)(signed char)(w >> 8) };
+				d[2 * i + 1] = f32x2{ (float)(signed char)(w >> 16), (float)((int)w >> 24) };
 			}
-		}
-		int oi[4], oq[4];
 #pragma unroll
-		for (int o = 0; o < 4; o++) {
-			// (d*h) >> 10 for d = u8-128, (x*h) >> 16 for int16 x: both as the high word of a 24x24-bit product of
-			// pre-shifted operands (d<<16 and h<<6: 24 and 20 bits; x<<8 and h<<8: 24 and 22 bits) -- one full-rate
-			// multiply per tap instead of multiply + shift
-			int si = 0, sq = 0;
+			for (int o = 0; o < 4; o++) {
+				const float kMagic = 12582912.0f;  // 2^23 + 2^22: room for negative sums
+				f32x2 acc = { kMagic, kMagic };
 #pragma unroll
-			for (int n = 0; n < 8; n++) {
-				si += mulhi24(kS1[n] << (IN16 ? 8 : 6), di[2 * o + n]);
-				sq += mulhi24(kS1[n] << (IN16 ? 8 : 6), dq[2 * o + n]);
+				for (int n = 0; n < 8; n++) {
+					const float hs = (float)kS1[n] * (1.0f / 1024.0f);
+					acc = __builtin_elementwise_fma(d[2 * o + n], f32x2{ hs, hs }, acc);
+				}
+				// acc's mantissa field holds 2^22 + sum; stage 2 wants sum << 8
+				oi[o] = (int)(__float_as_uint(acc.x) << 8) - (1 << 30);
+				oq[o] = (int)(__float_as_uint(acc.y) << 8) - (1 << 30);
 			}
-			oi[o] = (int)(int16_t)si << 8;
-			oq[o] = (int)(int16_t)sq << 8;
 		}
 		*reinterpret_cast<int4 *>(&y1i[4 * grp]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
 		*reinterpret_cast<int4 *>(&y1q[4 * grp]) = make_int4(oq[0], oq[1], oq[2], oq[3]);
