@@ -300,6 +300,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 					  17421, 13074, 6469, 494, -2817, -3198, -1844, -317, 451, 546 };
 	for (int n = 0; n < 20; n++)
 		c->taps.s2[n] = (int32_t)(cfg->filter_type ? wide[n] : narrow[n]) << 8;
+	for (int n = 0; n < 20; n++)
+		c->taps.f2[n] = (float)(cfg->filter_type ? wide[n] : narrow[n]) / 65536.0f;
 
 	// registration order, types and samples-per-bit of main.cpp:173-218
 	static const struct {

@@ -61,16 +61,19 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	constexpr int kTail = kTailBytes * kB;      // history bytes (56 complex samples)
 	constexpr int kChunks = (kTail + 8 * kB * kTileDec + 16 * kB + 15) / 16;
 	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
-	__shared__ __attribute__((aligned(16))) int32_t y1i[kY1Count];
-	__shared__ __attribute__((aligned(16))) int32_t y1q[kY1Count];
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+	__shared__ __attribute__((aligned(16))) f32x2 y1[kY1Count];  // stage-1 outputs as (I, Q) pairs of floats
+	const float kMagic = 12582912.0f;  // 2^23 + 2^22, see stage 1
 
 	const int s = blockIdx.y;
 	const int tile = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
 	const long nbytes = 8L * kB * m_total;
-	if (!IN16)  // MODE.FP_ROUND (fp32) = 2, round toward -inf: see stage 1.  The kernel has no other fp32 arithmetic.
-		__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);
+	// MODE.FP_ROUND (fp32) = 2, round toward -inf: see stage 1.  Every fp32 operation of this kernel is either one of
+	// those FMAs or exact.
+	__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);
 	const uint8_t *src = iq + (size_t)s * stride;
 
 	// ---- stage raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) into LDS, 16 B per lane, coalesced
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	constexpr int kGroups = (2 * kTileDec + 24 + 3) / 4;
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
 		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + kB * (12 + 16 * grp));
-		int oi[4], oq[4];
+		f32x2 oy[4];
 		if (IN16) {
 			int di[14], dq[14];
 #pragma unroll
@@ -116,8 +119,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 					si += mulhi24(kS1[n] << 8, di[2 * o + n]);
 					sq += mulhi24(kS1[n] << 8, dq[2 * o + n]);
 				}
-				oi[o] = (int)(int16_t)si << 8;
-				oq[o] = (int)(int16_t)sq << 8;
+				oy[o] = f32x2{ (float)(int)(int16_t)si, (float)(int)(int16_t)sq };
 			}
 		} else {
 			// u8 input: d = u8 - 128 has 8 bits and h 14, so d * (h / 1024) is exact in fp32, and with the wave's fp32
@@ -127,7 +129,6 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			// ONE instruction per tap -- and v_pk_fma_f32 does the I and the Q rail at once.  (The integer form costs a
 			// multiply and an add per tap and rail.)  The 8 taps sum to at most 8 * 1782, so acc stays in range and the
 			// int16 store of the reference (dsp_stuff.cpp:222) changes nothing.
-			typedef float f32x2 __attribute__((ext_vector_type(2)));
 			f32x2 d[14];
 #pragma unroll
 			for (int i = 0; i < 7; i++) {
@@ -137,45 +138,44 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			}
 #pragma unroll
 			for (int o = 0; o < 4; o++) {
-				const float kMagic = 12582912.0f;  // 2^23 + 2^22: room for negative sums
-				f32x2 acc = { kMagic, kMagic };
+				f32x2 acc = { kMagic, kMagic };  // 2^23 + 2^22: room for negative sums
 #pragma unroll
 				for (int n = 0; n < 8; n++) {
 					const float hs = (float)kS1[n] * (1.0f / 1024.0f);
 					acc = __builtin_elementwise_fma(d[2 * o + n], f32x2{ hs, hs }, acc);
 				}
-				// acc's mantissa field holds 2^22 + sum; stage 2 wants sum << 8
-				oi[o] = (int)(__float_as_uint(acc.x) << 8) - (1 << 30);
-				oq[o] = (int)(__float_as_uint(acc.y) << 8) - (1 << 30);
+				oy[o] = acc - f32x2{ kMagic, kMagic };  // exact
 			}
 		}
-		*reinterpret_cast<int4 *>(&y1i[4 * grp]) = make_int4(oi[0], oi[1], oi[2], oi[3]);
-		*reinterpret_cast<int4 *>(&y1q[4 * grp]) = make_int4(oq[0], oq[1], oq[2], oq[3]);
+		*reinterpret_cast<f32x4 *>(&y1[4 * grp]) = f32x4{ oy[0].x, oy[0].y, oy[1].x, oy[1].y };
+		*reinterpret_cast<f32x4 *>(&y1[4 * grp + 2]) = f32x4{ oy[2].x, oy[2].y, oy[3].x, oy[3].y };
 	}
 	__syncthreads();
 
-	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs LDS slots [8*tid + 4 + 2*o, +20)
-	int yi[28], yq[28];
+	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs LDS slots [8*tid + 4 + 2*o, +20).
+	// Same form as stage 1: acc = fma(y, h / 65536, acc) adds exactly floor(y * h / 65536) = (y * h) >> 16 -- the FMA
+	// rounds once, after the exact product, so it does not matter that y * h (up to 31 bits) is not an fp32 number; the
+	// 20 per-tap terms sum to less than 2^16, so acc stays in [2^23, 2^24).  One v_pk_fma_f32 per tap for both rails
+	// (the integer form: v_mul_hi_i32_i24 + an add per tap and rail).  The int16 store of the reference
+	// (dsp_stuff.cpp:196) is the low half of acc's mantissa: the magic constant has no bits there.
+	f32x2 y[28];
 #pragma unroll
-	for (int i = 0; i < 7; i++) {
-		const int4 a = *reinterpret_cast<const int4 *>(&y1i[8 * tid + 4 + 4 * i]);
-		const int4 b = *reinterpret_cast<const int4 *>(&y1q[8 * tid + 4 + 4 * i]);
-		yi[4 * i] = a.x; yi[4 * i + 1] = a.y; yi[4 * i + 2] = a.z; yi[4 * i + 3] = a.w;
-		yq[4 * i] = b.x; yq[4 * i + 1] = b.y; yq[4 * i + 2] = b.z; yq[4 * i + 3] = b.w;
+	for (int i = 0; i < 14; i++) {
+		const f32x4 a = *reinterpret_cast<const f32x4 *>(&y1[8 * tid + 4 + 2 * i]);
+		y[2 * i] = f32x2{ a.x, a.y };
+		y[2 * i + 1] = f32x2{ a.z, a.w };
 	}
 	int oI[4], oQ[4];
 	uint32_t outw[4];
 	bool trig[4];
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
-		int si = 0, sq = 0;
+		f32x2 acc = { kMagic, kMagic };
 #pragma unroll
-		for (int n = 0; n < 20; n++) {
-			si += mulhi24(taps.s2[n], yi[2 * o + n]);
-			sq += mulhi24(taps.s2[n], yq[2 * o + n]);
-		}
-		oI[o] = (int)(int16_t)si;
-		oQ[o] = (int)(int16_t)sq;
+		for (int n = 0; n < 20; n++)
+			acc = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n], taps.f2[n] }, acc);
+		oI[o] = (int)(int16_t)(__float_as_uint(acc.x) & 0xffffu);
+		oQ[o] = (int)(int16_t)(__float_as_uint(acc.y) & 0xffffu);
 		outw[o] = ((uint32_t)oI[o] & 0xffffu) | ((uint32_t)oQ[o] << 16);
 		trig[o] = (abs(oI[o]) + abs(oQ[o])) > thresh;
 	}
@@ -196,13 +196,11 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	// ---- the decimated sample BEFORE this submit's first one (it comes out of the carried raw history; zero history
 	// at stream start): the FM discriminator pass needs it for sample 0
 	if (tile == 0 && tid == 0) {
-		int si = 0, sq = 0;
+		f32x2 acc = { kMagic, kMagic };
 #pragma unroll
-		for (int n = 0; n < 20; n++) {
-			si += mulhi24(taps.s2[n], y1i[2 + n]);
-			sq += mulhi24(taps.s2[n], y1q[2 + n]);
-		}
-		prevdec[s] = ((uint32_t)(int16_t)si & 0xffffu) | ((uint32_t)(int16_t)sq << 16);
+		for (int n = 0; n < 20; n++)
+			acc = __builtin_elementwise_fma(y1[2 + n], f32x2{ taps.f2[n], taps.f2[n] }, acc);
+		prevdec[s] = (__float_as_uint(acc.x) & 0xffffu) | (__float_as_uint(acc.y) << 16);
 	}
 }
 
