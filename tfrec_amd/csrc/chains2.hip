@@ -1857,6 +1857,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		Dev3 cur = load_ahead(0), nxt = load_ahead(1);
 		int pd1 = 0, pd2 = 0;  // stage-1 outputs of the two samples before this step (same window)
 		while (j < count) {
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2  // instead: loop top -> recurrence | after candidates -> loop end
+			const long long pf_top = __builtin_readcyclecounter();
+#endif
 			// ---- (1) this step's inputs; the next two steps' are in flight
 			const int nv = cw.n - kStep * i < kStep ? cw.n - kStep * i : kStep;
 			const Dev3 nxt2 = load_ahead(2);
@@ -1900,6 +1903,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 #ifdef TFREC_AMD_PROFILE_WHB
 				const long long pf_a = __builtin_readcyclecounter();
 				pf_usteps++;
+#if TFREC_AMD_PROFILE_WHB == 2
+				pf_rec += pf_a - pf_top;
+#endif
 #endif
 				double y1 = f.yn, y2 = f.yn1;
 				// A full step: all feed-forward terms into registers first (the LDS reads are issued back to back, up to
@@ -1927,7 +1933,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					y1 = y;
 				}
 				__syncthreads();
-#ifdef TFREC_AMD_PROFILE_WHB
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB != 2
 				pf_rec += __builtin_readcyclecounter() - pf_a;
 #endif
 				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
@@ -1995,8 +2001,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					locked_here = true;
 				}
 			}
-#ifdef TFREC_AMD_PROFILE_WHB
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB != 2
 			pf_cand += __builtin_readcyclecounter() - pf_c;
+#endif
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2
+			const long long pf_post = __builtin_readcyclecounter();
 #endif
 			const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
 			const int dl2 = nv > 1 ? __builtin_amdgcn_readlane(dev, nv > 1 ? nv - 2 : 0) : pd1;
@@ -2058,6 +2067,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				nw = nnw;
 				nnw = read_win(j + 2);  // needed two windows from now: its latency is hidden
 			}
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2
+			pf_cand += __builtin_readcyclecounter() - pf_post;
+#endif
 		}
 	}
 	if (ln == 0) {
