@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void decim10_kernel(const uint8_t *__restrict_
 	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
 	const long m0 = (long)tile * kT10;
+	__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);  // fp32 rounding toward -inf (see below)
 	const long nbytes = 20L * n_out;
 	const uint8_t *src = iq + (size_t)s * stride;
 	// raw bytes [20*m0 - 112, 20*m0 + 20*T): LDS complex sample c <-> input sample 10*m0 - 56 + c
@@ -295,29 +296,33 @@ __global__ __launch_bounds__(256) void decim10_kernel(const uint8_t *__restrict_
 	__syncthreads();
 	// outputs m0 + 4*tid + o: x[10 m - 50 + n] is LDS sample 10*(4*tid + o) + 6 + n -> 90 samples from 40*tid + 6
 	const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + 2 * (40 * tid + 6));
-	int acc_i[4] = { 0, 0, 0, 0 }, acc_q[4] = { 0, 0, 0, 0 };
+	// (d*h) >> 10 per tap as one fp32 FMA in round-toward-minus-infinity mode, both rails per v_pk_fma_f32: see stage 1 of
+	// frontend_kernel.  The 60 taps' terms sum to less than 2^14.
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	const float kMagic = 12582912.0f;  // 2^23 + 2^22
+	f32x2 acc[4] = { { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic } };
 #pragma unroll
 	for (int w = 0; w < 45; w++) {  // one dword = two complex samples
-		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128), kept as d << 15
-		const int xi[2] = { (int)(v << 24) >> 9, (int)((v << 8) & 0xff000000u) >> 9 };
-		const int xq[2] = { (int)((v << 16) & 0xff000000u) >> 9, (int)(v & 0xff000000u) >> 9 };
+		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
+		const f32x2 x[2] = { f32x2{ (float)(signed char)(v), (float)(signed char)(v >> 8) },
+				     f32x2{ (float)(signed char)(v >> 16), (float)((int)v >> 24) } };
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
 			const int c = 2 * w + h;  // sample index relative to 40*tid + 6
 #pragma unroll
 			for (int o = 0; o < 4; o++) {
 				const int n = c - 10 * o;
-				if (n >= 0 && n < 60) {  // (d*h) >> 10 as the high word of (h << 7) * (d << 15), cf. stage 1
-					acc_i[o] += mulhi24(kTaps10[n] << 7, xi[h]);
-					acc_q[o] += mulhi24(kTaps10[n] << 7, xq[h]);
+				if (n >= 0 && n < 60) {
+					const float hs = (float)kTaps10[n] * (1.0f / 1024.0f);
+					acc[o] = __builtin_elementwise_fma(x[h], f32x2{ hs, hs }, acc[o]);
 				}
 			}
 		}
 	}
 	uint32_t ow[4];
 #pragma unroll
-	for (int o = 0; o < 4; o++)
-		ow[o] = ((uint32_t)(int16_t)acc_i[o] & 0xffffu) | ((uint32_t)(int16_t)acc_q[o] << 16);
+	for (int o = 0; o < 4; o++)  // the int16 store: the low half of the accumulator's mantissa
+		ow[o] = (__float_as_uint(acc[o].x) & 0xffffu) | (__float_as_uint(acc[o].y) << 16);
 	*reinterpret_cast<uint4 *>(out + (size_t)s * out_stride + m0 + 4 * tid) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
