@@ -293,13 +293,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	memset(&c->launch, 0, sizeof(c->launch));
 	memset(&c->win, 0, sizeof(c->win));
 
-	// second-stage taps: dsp_stuff.cpp:61-88 (narrow) / :91-117 (wide, -W), pre-shifted for v_mul_hi_i32_i24
+	// second-stage taps: dsp_stuff.cpp:61-88 (narrow) / :91-117 (wide, -W), as h / 65536
 	static const int16_t narrow[20] = { -1087, -1082, -1065, -451, 912, 2997, 5556, 8157, 10285, 11484,
 					    11484, 10285, 8157, 5556, 2997, 912, -451, -1065, -1082, -1087 };
 	static const int16_t wide[20] = { 546, 451, -317, -1844, -3198, -2817, 494, 6469, 13074, 17421,
 					  17421, 13074, 6469, 494, -2817, -3198, -1844, -317, 451, 546 };
-	for (int n = 0; n < 20; n++)
-		c->taps.s2[n] = (int32_t)(cfg->filter_type ? wide[n] : narrow[n]) << 8;
 	for (int n = 0; n < 20; n++)
 		c->taps.f2[n] = (float)(cfg->filter_type ? wide[n] : narrow[n]) / 65536.0f;
 

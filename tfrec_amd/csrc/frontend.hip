@@ -10,16 +10,21 @@
 // Exact integer semantics: with x = (u8-128)<<6,
 //   y1[k] = int16( sum_{n<8}  (x[2k-6+n]  * h1[n]) >> 16 )
 //   y2[m] = int16( sum_{n<20} (y1[2m-18+n] * h2[n]) >> 16 )
-// The per-tap floor shift forbids folding the symmetric taps or summing before shifting.  Stage 1 uses
-// ((u8-128)*h) >> 10 (identical value, the <<6 cancels); stage 2 uses v_mul_hi_i32_i24 on operands
-// pre-shifted by 8 bits: ((y<<8)*(h<<8)) >> 32 == (y*h) >> 16, one full-rate VALU op per tap + one add.
+// The per-tap floor shift forbids folding the symmetric taps or summing before shifting.  Both stages evaluate it as
+// ONE fp32 fused multiply-add per tap with the wave's fp32 rounding mode set to "toward -inf":
+//     acc = fma(x, h / 2^16, acc),   acc an integer in [2^23, 2^24) (one ulp = 1),  x and h / 2^16 exact in fp32
+// The FMA forms x*h/2^16 + acc exactly and rounds ONCE, downwards, to a multiple of acc's ulp: acc + floor(x*h / 2^16),
+// i.e. acc + ((x*h) >> 16) -- whatever the width of x*h.  The reference's int16 store of the sum is the low half of
+// acc's mantissa field (the starting value 2^23 + 2^22 has no bits there).  v_pk_fma_f32 does the I and the Q rail at
+// once: one VALU instruction per tap and complex sample, where the integer form (v_mul_hi_i32_i24 + add) took 3.5.
+// Stage 1 with u8 input uses ((u8-128)*h) >> 10 (identical value, the <<6 cancels).
 //
 // MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  The tile's
 // raw bytes (8 KiB + 112 B halo, the halo of the first tile comes from the previous submit's tail) are
-// staged into LDS with coalesced 16-byte loads, stage-1 outputs live only in LDS (pre-shifted int32, read
+// staged into LDS with coalesced 16-byte loads, stage-1 outputs live only in LDS ((I, Q) float pairs, read
 // back with ds_read_b128), stage-2 results leave as one 16-byte store per thread, and the trigger bits of
 // 64 consecutive samples are packed into one 64-bit word per wave-quarter with wave ballots.  No MFMA: the
-// path is a streaming stencil, bound by HBM bytes and integer VALU.
+// path is a streaming stencil with a per-tap rounding, bound by HBM bytes and VALU issue.
 #include "dsp_dev.h"
 
 namespace tfrec {
@@ -28,15 +33,6 @@ __device__ __constant__ double kAtanPolyFront[11] = TFREC_ATAN_POLY;  // see dsp
 
 // first-stage taps (dsp_stuff.cpp:119-130)
 __device__ __constant__ const int kS1[8] = { 2443, 6339, 11036, 14254, 14254, 11036, 6339, 2443 };
-
-__device__ __forceinline__ int mulhi24(int tap_s8, int y_s8)
-{
-	// bits [47:32] of the 24x24-bit signed product: full-rate VALU (v_mul_hi_i32 would be quarter rate and
-	// the compiler cannot prove the 24-bit ranges of run-time taps / LDS values by itself)
-	int r;
-	asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(r) : "s"(tap_s8), "v"(y_s8));
-	return r;
-}
 
 __device__ __forceinline__ unsigned long long spread4(unsigned long long x)
 {
@@ -103,23 +99,23 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + kB * (12 + 16 * grp));
 		f32x2 oy[4];
 		if (IN16) {
-			int di[14], dq[14];
+			// int16 input: the same FMA form (below) with x * (h / 65536); x * h has up to 30 bits, which the FMA does not
+			// care about (it rounds once, after the exact product), the 8 terms sum to less than 2^16 in magnitude, and
+			// the int16 store of the reference (dsp_stuff.cpp:222) -- it can wrap here -- is the low half of the mantissa
+			f32x2 x[14];
 #pragma unroll
-			for (int i = 0; i < 14; i++) {  // x << 8
-				di[i] = (int)(int16_t)(rp[i] & 0xffff) << 8;
-				dq[i] = ((int)rp[i] >> 16) << 8;
-			}
+			for (int i = 0; i < 14; i++)
+				x[i] = f32x2{ (float)(int)(int16_t)(rp[i] & 0xffff), (float)((int)rp[i] >> 16) };
 #pragma unroll
 			for (int o = 0; o < 4; o++) {
-				// (x*h) >> 16 as the high word of the 24x24-bit product of x<<8 and h<<8 (24 and 22 bits): one full-rate
-				// multiply per tap instead of multiply + shift
-				int si = 0, sq = 0;
+				f32x2 acc = { kMagic, kMagic };
 #pragma unroll
 				for (int n = 0; n < 8; n++) {
-					si += mulhi24(kS1[n] << 8, di[2 * o + n]);
-					sq += mulhi24(kS1[n] << 8, dq[2 * o + n]);
+					const float hs = (float)kS1[n] * (1.0f / 65536.0f);
+					acc = __builtin_elementwise_fma(x[2 * o + n], f32x2{ hs, hs }, acc);
 				}
-				oy[o] = f32x2{ (float)(int)(int16_t)si, (float)(int)(int16_t)sq };
+				oy[o] = f32x2{ (float)(int)(int16_t)(__float_as_uint(acc.x) & 0xffffu),
+					       (float)(int)(int16_t)(__float_as_uint(acc.y) & 0xffffu) };
 			}
 		} else {
 			// u8 input: d = u8 - 128 has 8 bits and h 14, so d * (h / 1024) is exact in fp32, and with the wave's fp32

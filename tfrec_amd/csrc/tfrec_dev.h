@@ -22,11 +22,9 @@ constexpr int kFrontThreads = 256;
 constexpr int kRawChunks = (kTailBytes + 8 * kTileDec + 16 + 15) / 16;  // 16-byte chunks staged per tile
 constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per channel (need 2*T+24)
 
-// Second-stage taps, pre-shifted by 8 for v_mul_hi_i32_i24 (see frontend.hip; the 10:1 stage of config 5 still uses
-// the integer form).
+// Second-stage taps as h / 65536 (exact in fp32): the multiplier of the FMA form of the FIR stages (frontend.hip).
 struct FrontTaps {
-	int32_t s2[20];
-	float f2[20];  // the same taps as h / 65536 (exact in fp32): multiplier of the fp32 form of stage 2 (frontend.hip)
+	float f2[20];
 };
 
 // ---- biquad (dsp_stuff.cpp:28-56); state as the reference's members, coefficients in FrontParams
