@@ -261,7 +261,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32+f64",
+            "dtype": "int32+f32+f64",  # integer FIR (evaluated exactly in fp32 FMAs) and slicers, fp64 biquads + discriminator
             "data": "synthetic (tfrec_amd.synth, SURVEY App. C recipe; %d distinct streams per GPU%s)" % (
                 unique, "" if unique == n_streams else " tiled over %d" % n_streams),
             "config": {
