@@ -1,5 +1,6 @@
-"""Cycle accounting of whb_demod_kernel (library built with -DTFREC_AMD_PROFILE_WHB, single-wave kernel:
-TFREC_AMD_WHB2=0).  usage: TFREC_AMD_LIB=.../lib_prof.so TFREC_AMD_WHB2=0 python whb_cycles.py [types_hex]"""
+"""Cycle accounting of whb_demod_kernel (library built with -DTFREC_AMD_PROFILE_WHB[=1]: the two printed parts are
+the recurrence and the candidate walk; =2: loop top -> recurrence, after the candidates -> loop end; =3: after the
+candidates -> state update, state update -> loop end).  usage: TFREC_AMD_LIB=.../lib_prof.so TFREC_AMD_WHB2=0 python whb_cycles.py [types_hex]"""
 import ctypes as C, sys
 sys.path.insert(0, '.')
 import torch

@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					y1 = y;
 				}
 				__syncthreads();
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB != 2
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB < 2
 				pf_rec += __builtin_readcyclecounter() - pf_a;
 #endif
 				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
@@ -2001,10 +2001,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					locked_here = true;
 				}
 			}
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB != 2
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB < 2
 			pf_cand += __builtin_readcyclecounter() - pf_c;
 #endif
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB >= 2
 			const long long pf_post = __builtin_readcyclecounter();
 #endif
 			const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
@@ -2020,6 +2020,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			last_dev = dl1;
 			pd2 = dl2;
 			pd1 = dl1;
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 3  // after the candidates -> state update | -> loop end
+			const long long pf_mid = __builtin_readcyclecounter();
+			pf_rec += pf_mid - pf_post;
+#endif
 			if (rssi_from < nv) {  // whb.cpp:677-678
 				const int I = (int)(int16_t)(iqw & 0xffff), Q = (int)iqw >> 16;
 				rssi_acc += wave_sum(ln >= rssi_from && ln < nv ? (unsigned long long)(uint32_t)(I * I + Q * Q) : 0ull);
@@ -2069,6 +2073,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			}
 #if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2
 			pf_cand += __builtin_readcyclecounter() - pf_post;
+#endif
+#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 3
+			pf_cand += __builtin_readcyclecounter() - pf_mid;
 #endif
 		}
 	}
