@@ -404,7 +404,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
 		ALLOC(c->d_ld16[set], chains * (size_t)T.slots * 32 * sizeof(int16_t));
 		if (whb)
-			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t));
+			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t) + 1024);  // + slack: whb_demod128 loads whole steps
 		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
 		const size_t wins = chains * (size_t)T.cap;
 		size_t off = 0;

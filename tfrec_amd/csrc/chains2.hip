@@ -2117,6 +2117,372 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_lds);
 }
 
+// The same kernel with 128 samples per step (two per lane): the per-step work outside the recurrence -- prefetch
+// addressing, barriers, state update, window bookkeeping: 40 % of whb_demod_kernel's cycles -- is paid half as often.
+__global__ __launch_bounds__(64) void whb_demod128_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
+						       long long sample_base, ChainLaunch L, int a, WinTables T,
+						       tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 256 B, used by the decoder tail
+	__shared__ double2 pb[128];
+	__shared__ double yl[128];
+	constexpr int kStep = 128;  // samples per iteration: two per lane (ln and ln + 64)
+	const int ln = threadIdx.x;
+	const int s = blockIdx.x;  // one wave per stream
+	const ChainParams &p = L.params[a];
+	ChainState &st = L.states[a][s];
+	const int c = a * n_streams + s;
+	const int M = n_blocks * kBlockDec;
+	const uint32_t *drow = dec + (size_t)s * dec_stride;
+	const int32_t *dvrow = dev32 + (size_t)s * T.slots * 32;
+	const BiquadCoef cavg = p.iir_avg;
+	const double spb = p.spb;
+	const double thr = 3 * spb / 4;        // whb.cpp:664
+	const int tmin = (int)floor(thr) + 1;  // smallest integer tdiff with tdiff > thr
+	// (int)((tdiff + spb/2) / spb) is an exact shift when spb is a power of two (the reference's WHB: 64.0)
+	const int spb_i = (int)spb;
+	const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
+	const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
+	// ---- per-stream state, wave-uniform
+	Biquad f = st.iir_avg;
+	int avg_of = st.avg_of, last_dev = st.last_dev;
+	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
+	// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
+	// additions are exact in any order: the lanes add their samples' power in integers.
+	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
+	unsigned long long rssi_acc = 0;       // ... and in this submit
+	int synced = st.synced;
+	// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
+	// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
+	uint32_t srr = __brev(st.sr);          // whb_decoder::sr, newest bit at the LSB
+	uint32_t nh = st.lfsr;                 // history of nrzs, newest at the LSB (whb.cpp:579)
+	const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
+	// sr_cnt / byte_cnt while the decoder has not locked since its last flush (they only matter before a stream's
+	// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
+	int sc = st.sr_cnt, bc = st.byte_cnt;
+	const int count = T.count[c];
+	const bool cont = T.cont[c] != 0;
+
+	auto wave_sum = [&](unsigned long long v) -> unsigned long long {
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1)
+			v += __shfl_xor(v, o, 64);
+		return v;
+	};
+	// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
+	auto feed = [&](uint32_t e, int len) -> bool {
+		const uint32_t emask = len >= 32 ? ~0u : (1u << len) - 1u;
+		const uint32_t nrun = __brev((e ^ kmask) & emask) >> (32 - len);           // nrzs of the run, newest at the LSB
+		const unsigned long long hn = ((unsigned long long)nh << len) | nrun;
+		const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;    // descrambled bits, whb.cpp:578
+		const unsigned long long sv = ((unsigned long long)srr << len) | orun;
+		const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
+		nh = (uint32_t)hn;
+		srr = (uint32_t)sv;
+		return __ballot(hit) != 0ull;
+	};
+	// sr_cnt / byte_cnt over `len` bits without a sync word (whb.cpp:590-596)
+	auto count_bits = [&](int len) {
+		if (sc >= 0) {
+			const int i0 = (8 - sc) & 7;  // first bit of the run that finds sr_cnt == 0
+			bc += i0 < len ? (len - 1 - i0) / 8 + 1 : 0;
+			sc = (sc + len) & 7;
+		}
+	};
+	struct Win {
+		int og, n, nch, slot0, closed;
+	};
+	auto read_win = [&](int jj) -> Win {
+		Win r;
+		const int jc = jj < count ? jj : (count > 0 ? count - 1 : 0);
+		r.og = T.open[(size_t)c * T.cap + jc];
+		const int close = T.close[(size_t)c * T.cap + jc];
+		r.closed = close < M;
+		r.n = (r.closed ? close : M - 1) - r.og + 1;
+		r.nch = (r.n + kStep - 1) / kStep;
+		r.slot0 = win_slot0(r.og, jc);
+		return r;
+	};
+	// the lane's two stage-1 outputs of a step (samples ln and ln + 64) and the two before each
+	struct Dev6 {
+		int a0, a1, a2, b0, b1, b2;
+	};
+	auto load_dev = [&](int slot0, int i) -> Dev6 {
+		const int idx = slot0 * 32 + kStep * i + ln;
+		Dev6 r;
+		r.a0 = dvrow[idx];
+		r.a1 = dvrow[idx > 0 ? idx - 1 : 0];
+		r.a2 = dvrow[idx > 1 ? idx - 2 : 0];
+		r.b0 = dvrow[idx + 64];
+		r.b1 = dvrow[idx + 63];
+		r.b2 = dvrow[idx + 62];
+		return r;
+	};
+	if (count > 0) {
+		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);
+		int j = 0, i = 0, nent = 0;
+		auto load_ahead = [&](int ahead) -> Dev6 {
+			int ii = i + ahead;
+			if (ii < cw.nch)
+				return load_dev(cw.slot0, ii);
+			ii -= cw.nch;
+			if (j + 1 < count) {
+				if (ii < nw.nch)
+					return load_dev(nw.slot0, ii);
+				ii -= nw.nch;
+				if (j + 2 < count && ii < nnw.nch)
+					return load_dev(nnw.slot0, ii);
+			}
+			return load_dev(cw.slot0, 0);
+		};
+		Dev6 cur = load_ahead(0), nxt = load_ahead(1);
+		int pd1 = 0, pd2 = 0;  // stage-1 outputs of the two samples before this step (same window)
+		while (j < count) {
+			// ---- (1) this step's inputs; the next two steps' are in flight
+			const int nv = cw.n - kStep * i < kStep ? cw.n - kStep * i : kStep;
+			const int nvA = nv < 64 ? nv : 64, nvB = nv - 64;  // valid samples of the two halves (nvB may be <= 0)
+			const Dev6 nxt2 = load_ahead(2);
+			const int og = cw.og, n = cw.n;
+			uint32_t iqA = 0, iqB = 0;  // the lane's decimated samples (rssi: only while the decoder is locked)
+			bool have_iq = false;
+			if (synced) {
+				iqA = drow[og + kStep * i + ln];
+				iqB = drow[og + kStep * i + 64 + ln < M ? og + kStep * i + 64 + ln : M - 1];
+				have_iq = true;
+			}
+			const int devA = cur.a0, devB = cur.b0;
+			const int devm1A = ln >= 1 ? cur.a1 : pd1;
+			const int devm2A = ln >= 2 ? cur.a2 : (ln == 1 ? pd1 : pd2);
+			const int devm1B = cur.b1, devm2B = cur.b2;
+			if (i == 0) {
+				if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
+					rssi_d = 0;
+					rssi_acc = 0;
+					step0 = 0;
+					last_peak = 0;
+				}
+				if (ln == 0) {
+					WhbStart ws;
+					ws.sr = __brev(srr);
+					ws.lfsr = nh;
+					ws.sr_cnt = sc;
+					ws.byte_cnt = bc;
+					ws.synced = synced;
+					ws.pad_[0] = ws.pad_[1] = ws.pad_[2] = 0;
+					T.whbstart[(size_t)s * T.cap + j] = ws;
+				}
+			}
+			// dev > last_dev (whb.cpp:663); the window's first sample compares with the carried last_dev
+			const bool riseA = devA > ((i == 0 && ln == 0) ? last_dev : devm1A);
+			const bool riseB = devB > devm1B;
+			const bool unsynced0 = !synced;
+			int avgnA = avg_of, avgnB = avg_of;
+			if (unsynced0) {
+				const bool first = i == 0;  // the window's first samples continue the carried filter inputs
+				{
+					const double dn = 0.5 * (double)devA;  // whb.cpp:654
+					const double dn1 = (first && ln == 0) ? f.dn1 : 0.5 * (double)devm1A;
+					const double dn2 = (first && ln == 0) ? f.dn2 : ((first && ln == 1) ? f.dn1 : 0.5 * (double)devm2A);
+					pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
+				}
+				{
+					const double dn = 0.5 * (double)devB, dn1 = 0.5 * (double)devm1B, dn2 = 0.5 * (double)devm2B;
+					pb[64 + ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
+				}
+				__syncthreads();
+				// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association): 64 samples at
+				// a time with all feed-forward terms in registers first (see whb_demod_kernel), then what is left
+				double y1 = f.yn, y2 = f.yn1;
+				int k0 = 0;
+#pragma unroll 1
+				for (; k0 + 64 <= nv; k0 += 64) {
+					double2 v[64];
+#pragma unroll
+					for (int k = 0; k < 64; k++)
+						v[k] = pb[k0 + k];
+#pragma unroll
+					for (int k = 0; k < 64; k++) {
+						const double y = ((v[k].y + cavg.a1 * y1) + v[k].x) + cavg.a2 * y2;
+						yl[k0 + k] = y;
+						y2 = y1;
+						y1 = y;
+					}
+				}
+#pragma unroll 4
+				for (int k = k0; k < nv; k++) {
+					const double2 v = pb[k];
+					const double y = ((v.y + cavg.a1 * y1) + v.x) + cavg.a2 * y2;
+					yl[k] = y;
+					y2 = y1;
+					y1 = y;
+				}
+				__syncthreads();
+				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
+				avgnA = (int)yl[ln];
+				avgnB = (int)yl[64 + ln];
+			}
+			// ---- (3) + (4): candidates dev < avg_of && dev > last_dev, half by half
+			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
+			const long long base_step = step0 + (long long)kStep * i;
+			bool locked_here = false;
+			int rssi_from = synced ? 0 : kStep;  // first sample of the step that counts for the rssi
+#pragma unroll
+			for (int half = 0; half < 2; half++) {
+				const int dev = half ? devB : devA;
+				const bool rise = half ? riseB : riseA;
+				const int nvh = half ? nvB : nvA;
+				const int kofs = 64 * half;
+				// (a lock in the first half froze avg_of: the second half is tested against it)
+				const int avgn = synced ? avg_of : (half ? avgnB : avgnA);
+				unsigned long long mask = __ballot(ln < nvh && dev < avgn && rise);
+				while (mask) {
+					const long long kmin = last_peak + tmin - base_step - kofs;  // first k with tdiff > 3*spb/4
+					if (kmin > 63)
+						break;
+					if (kmin > 0)
+						mask &= ~0ull << (int)kmin;
+					if (!mask)
+						break;
+					const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+					mask &= mask - 1;
+					const int kg = kofs + k;  // sample index in the step
+					const int tdiff = (int)(base_step + kg - last_peak);
+					// whb.cpp:666-673: one 0, then (bit0 - 1) ones
+					const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
+					const int len = bit0 > 1 ? bit0 : 1;
+					if (ln == 0) {
+						if (len < kWhbRunEsc) {
+							ent[nent] = (uint16_t)len;
+						} else {
+							ent[nent] = (uint16_t)kWhbRunEsc;
+							ent[nent + 1] = (uint16_t)((uint32_t)len & 0xffff);
+							ent[nent + 2] = (uint16_t)((uint32_t)len >> 16);
+						}
+					}
+					nent += len < kWhbRunEsc ? 1 : 3;
+					bool hit = feed(~1u, len < 32 ? len : 32);
+					for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
+						hit = feed(~0u, rest < 32 ? rest : 32) || hit;
+					if (!synced)
+						count_bits(len);
+					last_peak = base_step + kg;
+					if (!synced && hit) {  // the decoder locked at sample kg: rssi counts from there on (:677)
+						synced = 1;
+						rssi_from = kg;
+						if (!have_iq) {
+							iqA = drow[og + kStep * i + ln];
+							iqB = drow[og + kStep * i + 64 + ln < M ? og + kStep * i + 64 + ln : M - 1];
+							have_iq = true;
+						}
+						// the average stops after sample kg (whb.cpp:653): state and avg_of as of kg, and the rest of
+						// the step's candidates against the frozen avg_of
+						const double yk = yl[kg], ykm1 = yl[kg > 0 ? kg - 1 : 0];
+						const int dk = __builtin_amdgcn_readlane(dev, k);
+						// the sample before kg: same half, or the first half's last lane
+						const int dkm1 = k > 0 ? __builtin_amdgcn_readlane(dev, k > 0 ? k - 1 : 0)
+								       : (half ? __builtin_amdgcn_readlane(devA, 63) : 0);
+						f.yn1 = kg > 0 ? ykm1 : f.yn;
+						f.yn = yk;
+						f.dn2 = kg > 0 ? 0.5 * (double)dkm1 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
+						f.dn1 = 0.5 * (double)dk;
+						avg_of = (int)yk;
+						mask = __ballot(ln < nvh && ln > k && dev < avg_of && rise);
+						locked_here = true;
+					}
+				}
+			}
+			// the step's last two samples
+			const int dl1 = nv > 64 ? __builtin_amdgcn_readlane(devB, nv > 64 ? nv - 65 : 0) : __builtin_amdgcn_readlane(devA, nv - 1);
+			const int dl2 = nv > 65 ? __builtin_amdgcn_readlane(devB, nv > 65 ? nv - 66 : 0)
+					       : (nv > 1 ? __builtin_amdgcn_readlane(devA, nv > 1 ? (nv == 65 ? 63 : nv - 2) : 0) : pd1);
+			if (unsynced0 && !locked_here) {  // the whole step went through the average
+				const double ye = yl[nv - 1], yem1 = yl[nv > 1 ? nv - 2 : 0];
+				f.yn1 = nv > 1 ? yem1 : f.yn;
+				f.yn = ye;
+				f.dn2 = nv > 1 ? 0.5 * (double)dl2 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
+				f.dn1 = 0.5 * (double)dl1;
+				avg_of = (int)ye;
+			}
+			last_dev = dl1;
+			pd2 = dl2;
+			pd1 = dl1;
+			if (rssi_from < nv) {  // whb.cpp:677-678
+				const int IA = (int)(int16_t)(iqA & 0xffff), QA = (int)iqA >> 16;
+				const int IB = (int)(int16_t)(iqB & 0xffff), QB = (int)iqB >> 16;
+				const unsigned long long pa = ln >= rssi_from && ln < nvA ? (unsigned long long)(uint32_t)(IA * IA + QA * QA) : 0ull;
+				const unsigned long long pq = 64 + ln >= rssi_from && ln < nvB ? (unsigned long long)(uint32_t)(IB * IB + QB * QB) : 0ull;
+				rssi_acc += wave_sum(pa + pq);
+			}
+			if (i == cw.nch - 1) {  // last sample of the window in this submit
+				WinResult res;
+				res.nbits = nent;
+				res.closed = 0;
+				long long rssi_out = 0;
+				if (cw.closed) {  // timeout_cnt reached 0, whb.cpp:691-702
+					if (synced) {
+						(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
+						rssi_out = (long long)(rssi_d + (double)rssi_acc);
+						res.closed = 1;
+						srr = 0;
+						synced = 0;
+						sc = -1;
+						bc = 0;
+					}
+					rssi_d = 0;
+					rssi_acc = 0;
+					step0 = 0;
+					last_peak = 0;
+				} else {  // window continues in the next submit
+					rssi_d += (double)rssi_acc;
+					rssi_acc = 0;
+					step0 += n;
+				}
+				res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
+				res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
+				res.lbi_out = 0;
+				res.first_cand_g = -1;
+				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
+				res.resume = -1;
+				if (ln == 0)
+					T.result[(size_t)c * T.cap + j] = res;
+				nent = 0;
+			}
+			cur = nxt;
+			nxt = nxt2;
+			if (++i >= cw.nch) {
+				j++;
+				i = 0;
+				cw = nw;
+				nw = nnw;
+				nnw = read_win(j + 2);  // needed two windows from now: its latency is hidden
+			}
+		}
+	}
+	if (ln == 0) {
+		const uint32_t lw = drow[M - 1];
+		st.prev_i = (int)(int16_t)(lw & 0xffff);
+		st.prev_q = (int)lw >> 16;
+		st.timeout_cnt = T.timeout_next[c];
+		st.last_dev = last_dev;
+		st.avg_of = avg_of;
+		st.step = (unsigned long long)step0;
+		st.last_peak = (unsigned long long)last_peak;
+		st.rssi_d = rssi_d;
+		st.iir_avg = f;
+	}
+	// ---- decoder tail: the stream's windows, one per lane, then the stream's commit (lane 0)
+	__threadfence();  // lane 0's runs, results and start registers
+	__syncthreads();
+	for (int j = ln; j < count; j += 64)
+		whb_decode_window(s, j, n_streams, L, a, T, rdata_lds + 256 * ln);
+	__threadfence();
+	__syncthreads();
+	if (ln == 0)
+		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_lds);
+}
+
+
 // ------------------------------------------------------------------------------------------------ K5
 // decoder::store_bit / flush for TFA_1 and the TFA_2 family, in two stages:
 //   K5a decode_kernel  lane per WINDOW: every window of a chain ends with decoder::flush, which re-arms the decoder
@@ -2522,8 +2888,17 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 				// their whole life (10.4 -> 8.5 ms when the cap was introduced, then 22 KB = 7 per CU; with the deep layout
 				// 16 KB measures 3 % better than 22 KB, and 30 KB 8 % worse).  TFREC_AMD_WHB_LDS raises it.
 				static const int whb_lds = std::max(64 * 256, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
-				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
-						   n_blocks, sample_base, L, a, T, events, eb, flags);
+				// 128 samples per step: the kernel itself is 7-10 % faster, and a batch with only WHB registered with it
+				// (6.4 instead of 7.1 ms); beside the TFA chains the batch came out 2 % slower (9.65 vs 9.45 ms), so
+				// it is the default only when WHB runs alone.  TFREC_AMD_WHB128 = 0 / 1 forces one or the other.
+				static const int step128_env = env_int("TFREC_AMD_WHB128", -1, -1, 1);
+				const bool step128 = step128_env >= 0 ? step128_env != 0 : !(has_tfa1 || has_tfa2);
+				if (step128)
+					hipLaunchKernelGGL(whb_demod128_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32,
+							   n_streams, n_blocks, sample_base, L, a, T, events, eb, flags);
+				else
+					hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
+							   n_blocks, sample_base, L, a, T, events, eb, flags);
 				mark(13, P.aux);
 				mark(14, P.aux);
 				mark(15, P.aux);
