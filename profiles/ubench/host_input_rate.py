@@ -1,4 +1,4 @@
-"""PCIe-inclusive rate: batches fed from page-locked HOST memory through tfrec_amd_submit_host with the depth-2 FIFO
+"""PCIe-inclusive rate: batches fed from page-locked HOST memory with tfrec_amd_submit_host, two submits in flight
 (what the file feeder of tfrec_amd/host/gpu_engine.cpp does).  usage: host_input_rate.py [streams] [blocks] [steps]"""
 import ctypes as C
 import sys

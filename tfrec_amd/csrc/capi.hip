@@ -54,7 +54,7 @@ struct tfrec_amd_ctx {
 	tfrec_amd_config cfg;
 	ChainLaunch launch;
 	FrontTaps taps;
-	// front-end outputs, double-buffered like the event buffers: the front end of submit k+1 (its own stream)
+	// front-end outputs, one set per submit in flight like the event buffers: the front end of submit k+2 (its own stream)
 	// runs beside the demodulator chains of submit k
 	uint32_t *d_dec[kSets] = {};
 	size_t dec_stride = 0;  // uint32 units
