@@ -161,8 +161,27 @@ int tfrec_amd_rssi_db(int slot, int64_t rssi_raw);
 int tfrec_amd_read_stage0(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_t n_pairs);
 /* Parity/debug: copy the decimated int16 IQ of the last submit for one stream (n_pairs*2 int16). */
 int tfrec_amd_read_decimated(tfrec_amd_ctx *ctx, int stream, int16_t *out, size_t n_pairs);
-/* Samples whose FM-discriminator truncation was closer than 1e-9 to an integer boundary. */
+/* fm_dev (dsp_stuff.cpp:284-292) is (int)(atan2(cj, cr) * 16384/pi) in double.  The device evaluates its own atan2
+ * (4e-12 in the scaled angle); every sample whose scaled angle lies within 1e-9 of an integer is decided by an exact
+ * slow path (double-double; the result the reference computes under a correctly rounded atan2), and the decisions are
+ * logged (the first 62 per submit) and checked against THIS host's libm -- the arithmetic the reference binary uses
+ * here -- when the submit is drained.  A run certifies itself: host_mismatch == 0 means every logged decision equals
+ * the reference's; `undecidable` counts samples so close to a rounding midpoint of atan2 (< 0.06 ulp) that glibc's
+ * documented error (0.55 ulp) lets the reference itself round either way (expected ~2e-13 per sample). */
+typedef struct {
+	uint64_t resolved;      /* samples decided by the slow path (of the submits drained so far) */
+	uint64_t host_verified; /* ... of which were logged and compared with the host's libm */
+	uint64_t host_mismatch; /* ... and differed from it */
+	uint64_t undecidable;   /* slow-path samples within 0.06 ulp of an atan2 rounding midpoint */
+	uint64_t reserved[4];
+} tfrec_amd_fm_stats;
+int tfrec_amd_get_fm_stats(tfrec_amd_ctx *ctx, tfrec_amd_fm_stats *out);
+/* Samples decided by the slow path, including submits not drained yet (waits for them). */
 int tfrec_amd_atan_uncertain(tfrec_amd_ctx *ctx, uint64_t *n);
+/* Parity probe: the device's fm_dev on n 16-byte records -- kind 0: int32 quadruples (ar, aj, br, bj) = the arguments
+ * of dsp_stuff.cpp:284; kind 1: int64 pairs (cr, cj) = its cross terms (:288-289), for directions no int16 quadruple
+ * reaches.  out[n].  No context needed.  stats (may be NULL): as above, for this call. */
+int tfrec_amd_fm_dev_probe(int device, int kind, const void *records, size_t n, int32_t *out, tfrec_amd_fm_stats *stats);
 int tfrec_amd_get_timings(tfrec_amd_ctx *ctx, tfrec_amd_timings *out);
 /* Cumulative counters of the speculative stages (window-parallel pipeline only).  They only describe how the work
  * was done -- results do not depend on them. */

@@ -13,6 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liboracle.so")
 REF_DRIVER = os.path.join(_HERE, "_ref", "ref_driver")
+FM_BOUNDARY = os.path.join(_HERE, "_build", "fm_boundary")            # near-boundary discriminator input search
+FM_RESOLVE_CHECK = os.path.join(_HERE, "_build", "fm_resolve_check")  # host build of the product's exact fm_dev slow path
 REFERENCE_DIR = "/root/reference"
 
 SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
@@ -46,8 +48,10 @@ class Data(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the C restatement (and, where /root/reference exists, the real reference harness)."""
-    src = [os.path.join(_HERE, f) for f in ("tfrec_oracle.c", "tfrec_oracle.h", "Makefile")]
-    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    src = [os.path.join(_HERE, f) for f in ("tfrec_oracle.c", "tfrec_oracle.h", "Makefile", "fm_boundary.c", "fm_resolve_check.cpp")]
+    src += [os.path.join(os.path.dirname(_HERE), "tfrec_amd", "csrc", f) for f in ("fm_resolve.h", "fm_resolve_tables.h")]
+    outs = [_SO, FM_BOUNDARY, FM_RESOLVE_CHECK]
+    stale = any(not os.path.exists(o) for o in outs) or any(os.path.getmtime(s) > os.path.getmtime(o) for s in src for o in outs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
     if os.path.isdir(REFERENCE_DIR):

@@ -58,6 +58,11 @@ class Stats(C.Structure):
                 ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
+class FmStats(C.Structure):
+    _fields_ = [("resolved", C.c_uint64), ("host_verified", C.c_uint64), ("host_mismatch", C.c_uint64),
+                ("undecidable", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
 EVENT_DTYPE = np.dtype(
     [
         ("stream", "<u4"),
@@ -79,7 +84,7 @@ EXPORTS = (
     "tfrec_amd_submit_device", "tfrec_amd_submit_host", "tfrec_amd_sync", "tfrec_amd_drain_events",
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
     "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_get_layout", "tfrec_amd_host_alloc",
-    "tfrec_amd_host_free", "tfrec_amd_read_stage0",
+    "tfrec_amd_host_free", "tfrec_amd_read_stage0", "tfrec_amd_get_fm_stats", "tfrec_amd_fm_dev_probe",
 )
 
 _lib = None
@@ -130,6 +135,8 @@ def load_library(build: bool = True):
     L.tfrec_amd_read_thresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.tfrec_amd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.tfrec_amd_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.tfrec_amd_get_fm_stats.argtypes = [C.c_void_p, C.POINTER(FmStats)]
+    L.tfrec_amd_fm_dev_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(FmStats)]
     _lib = L
     return L
 
@@ -229,6 +236,13 @@ class Receiver:
         _check(self.L, self.L.tfrec_amd_atan_uncertain(self.h, C.byref(n)))
         return int(n.value)
 
+    def fm_stats(self) -> dict:
+        """fm_dev samples decided by the exact slow path / checked against the host's libm at drain / differing from it /
+        too close to an atan2 rounding midpoint for glibc's error bound (tfrec_amd_get_fm_stats)."""
+        st = FmStats()
+        _check(self.L, self.L.tfrec_amd_get_fm_stats(self.h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in FmStats._fields_[:4]}
+
     def thresh(self, stream: int) -> int:
         v = C.c_int(0)
         _check(self.L, self.L.tfrec_amd_read_thresh(self.h, stream, C.byref(v)))
@@ -250,6 +264,18 @@ class Receiver:
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
         return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:5]}
+
+
+def fm_dev_probe(records: np.ndarray, device: int = 0, cross: bool = False):
+    """The device's fm_dev (dsp_stuff.cpp:284-292) on int32 quadruples [n, 4] = (ar, aj, br, bj), or (cross=True) on
+    int64 cross terms [n, 2] = (cr, cj) -> (int32[n], stats)."""
+    L = load_library()
+    q = (np.ascontiguousarray(records, dtype=np.int64).reshape(-1, 2) if cross
+         else np.ascontiguousarray(records, dtype=np.int32).reshape(-1, 4))
+    out = np.empty(len(q), dtype=np.int32)
+    st = FmStats()
+    _check(L, L.tfrec_amd_fm_dev_probe(device, 1 if cross else 0, q.ctypes.data, len(q), out.ctypes.data, C.byref(st)))
+    return out, {n: int(getattr(st, n)) for n, _ in FmStats._fields_[:4]}
 
 
 def event_tuples(events: np.ndarray, stream: int | None = None):

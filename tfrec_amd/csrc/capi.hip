@@ -23,6 +23,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
+hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32_t *out, EventBuf *eb, int kind);
 hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stride, unsigned long long *mask,
 			    size_t mask_stride, int n_streams, int n_blocks, FskState *fsk, int wmax);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
@@ -49,6 +50,10 @@ static int hip_fail(hipError_t e, const char *what)
 		if (e_ != hipSuccess)                  \
 			return hip_fail(e_, #call);    \
 	} while (0)
+
+struct FmTotals {
+	unsigned long long resolved = 0, verified = 0, mismatch = 0, undecidable = 0;
+};
 
 struct tfrec_amd_ctx {
 	tfrec_amd_config cfg;
@@ -96,14 +101,15 @@ struct tfrec_amd_ctx {
 	size_t in16_stride = 0;  // uint32 units
 	uint8_t *d_tail10[kSets] = {};
 	bool in10x = false;
-	// Two event buffer sets: a submit may be queued while the host still drains the previous one (FIFO, depth 2)
+	// One event buffer set per submit in flight (FIFO of depth TFREC_AMD_FIFO_DEPTH): submits may be queued while the
+	// host still drains an older one
 	tfrec_amd_event *d_events[kSets] = {};
 	EventBuf *d_eb[kSets] = {};
 	EventBuf *d_eb_fresh = nullptr;       // { 0, max_events, 0 }: copied over a set's EventBuf when a submit starts
 	tfrec_amd_event *h_events = nullptr;  // pinned staging for the drain
 	EventBuf *h_eb = nullptr;
 	hipEvent_t done[kSets][3] = {};  // end of the submit that owns the set, on the cs / aux / t1 stream
-	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..2)
+	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..TFREC_AMD_FIFO_DEPTH)
 	int last_drained = -1;
 	uint8_t *d_stage[kSets] = {};  // tfrec_amd_submit_host: device staging, one per buffer set
 	size_t stage_bytes[kSets] = {};
@@ -115,7 +121,9 @@ struct tfrec_amd_ctx {
 	hipStream_t t1 = nullptr;  // TFA_1 slicer chain (needs no biquad stage: runs beside the TFA_2-family biquads)
 	bool whb_active = false;
 	bool timed = false;
-	unsigned long long uncertain_total = 0;
+	// fm_dev samples decided by the exact slow path: all / checked against this host's libm at drain / differing from
+	// it / closer to a rounding midpoint than glibc's error bound
+	FmTotals fm;
 };
 
 // ---- biquad coefficients (iir2::set, dsp_stuff.cpp:36-45) in the arithmetic of the reference's normative
@@ -160,6 +168,22 @@ static int d2i_host(double v)
 	if (!(v > -2147483649.0 && v < 2147483648.0))
 		return (int)0x80000000;
 	return (int)v;
+}
+
+// The discriminator samples the device decided with its exact slow path (fm_resolve.h), checked against the libm of
+// THIS host -- the arithmetic the reference binary would use here (dsp_stuff.cpp:284-292 as compiled: DESIGN.md 1).
+static void account_fm_log(FmTotals *t, const EventBuf &eb)
+{
+	t->resolved += eb.uncertain;
+	t->undecidable += eb.fm_undecidable;
+	const uint32_t n = std::min<uint32_t>(eb.fm_logged, (uint32_t)kFmLogCap);
+	const double scale = 16384.0 * (1.0 / M_PI);
+	for (uint32_t k = 0; k < n; k++) {
+		const int want = d2i_host(atan2(eb.fm_log[k].cj, eb.fm_log[k].cr) * scale);
+		t->verified++;
+		if (want != eb.fm_log[k].result)
+			t->mismatch++;
+	}
 }
 
 extern "C" {
@@ -489,7 +513,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	(void)prio_lo;
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
-		EventBuf eb = { 0u, (uint32_t)cfg->max_events, 0ull };
+		EventBuf eb;
+		memset(&eb, 0, sizeof(eb));
+		eb.capacity = (uint32_t)cfg->max_events;
 		// (int16 history of the 10x path: zero; raw u8 history of its 10:1 stage: 128)
 		if (hipMemset(c->d_tail[0], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
 		    hipMemset(c->d_tail[1], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
@@ -750,7 +776,7 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	c->head = (c->head + 1) % kSets;
 	c->inflight--;
 	c->last_drained = set;
-	c->uncertain_total += eb.uncertain;
+	account_fm_log(&c->fm, eb);
 	if (c->win[set].overflow) {
 		int32_t wov = 0;
 		HIPCHK(hipMemcpyAsync(c->h_eb, c->win[set].overflow, 4, hipMemcpyDeviceToHost, c->cp));
@@ -812,13 +838,67 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 	int rc = tfrec_amd_sync(c);
 	if (rc)
 		return rc;
-	*n = c->uncertain_total;
+	*n = c->fm.resolved;
 	for (int k = 0; k < c->inflight; k++) {  // submits not drained yet
 		EventBuf eb;
 		HIPCHK(hipMemcpy(&eb, c->d_eb[(c->head + k) % kSets], sizeof(eb), hipMemcpyDeviceToHost));
 		*n += eb.uncertain;
 	}
 	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_get_fm_stats(tfrec_amd_ctx *c, tfrec_amd_fm_stats *out)
+{
+	if (!c || !out)
+		return TFREC_AMD_E_INVAL;
+	memset(out, 0, sizeof(*out));
+	out->resolved = c->fm.resolved;
+	out->host_verified = c->fm.verified;
+	out->host_mismatch = c->fm.mismatch;
+	out->undecidable = c->fm.undecidable;
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_fm_dev_probe(int device, int kind, const void *quads_v, size_t n, int32_t *out, tfrec_amd_fm_stats *stats)
+{
+	const int32_t *quads = (const int32_t *)quads_v;
+	if (!quads || !out || n == 0 || n > (1u << 26) || kind < 0 || kind > 1)
+		return TFREC_AMD_E_INVAL;
+	HIPCHK(hipSetDevice(device));
+	int32_t *d_q = nullptr, *d_o = nullptr;
+	EventBuf *d_eb = nullptr;
+	int rc = TFREC_AMD_OK;
+	FmTotals tmp;
+	if (hipMalloc((void **)&d_q, n * 16) != hipSuccess || hipMalloc((void **)&d_o, n * 4) != hipSuccess ||
+	    hipMalloc((void **)&d_eb, sizeof(EventBuf)) != hipSuccess)
+		rc = TFREC_AMD_E_NOMEM;
+	// In pieces, so that the log (the first kFmLogCap slow-path decisions of a launch) does not saturate early; a caller
+	// that wants EVERY sample checked compares `out` with its own reference.
+	const size_t piece = 4096;
+	if (rc == TFREC_AMD_OK && hipMemcpy(d_q, quads, n * 16, hipMemcpyHostToDevice) != hipSuccess)
+		rc = TFREC_AMD_E_HIP;
+	for (size_t o = 0; o < n && rc == TFREC_AMD_OK; o += piece) {
+		const size_t m = std::min(piece, n - o);
+		EventBuf eb;
+		if (hipMemset(d_eb, 0, sizeof(EventBuf)) != hipSuccess || launch_fm_probe(nullptr, d_q + 4 * o, m, d_o + o, d_eb, kind) != hipSuccess ||
+		    hipMemcpy(&eb, d_eb, sizeof(eb), hipMemcpyDeviceToHost) != hipSuccess)
+			rc = hip_fail(hipGetLastError(), "fm_probe");
+		else
+			account_fm_log(&tmp, eb);
+	}
+	if (rc == TFREC_AMD_OK && hipMemcpy(out, d_o, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+		rc = TFREC_AMD_E_HIP;
+	(void)hipFree(d_q);
+	(void)hipFree(d_o);
+	(void)hipFree(d_eb);
+	if (stats) {
+		memset(stats, 0, sizeof(*stats));
+		stats->resolved = tmp.resolved;
+		stats->host_verified = tmp.verified;
+		stats->host_mismatch = tmp.mismatch;
+		stats->undecidable = tmp.undecidable;
+	}
+	return rc;
 }
 
 int tfrec_amd_read_thresh(tfrec_amd_ctx *c, int stream, int *thresh)

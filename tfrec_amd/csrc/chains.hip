@@ -142,10 +142,7 @@ __device__ __forceinline__ void chain_body(const uint32_t *__restrict__ dec, siz
 				}
 				timeout_cnt = p.window;
 			}
-			bool unc;
-			const int dev0 = fm_dev(I, Q, pI, pQ, &unc, kAtanPolySerial);
-			if (unc)
-				atomicAdd(&eb->uncertain, 1ull);
+			const int dev0 = fm_dev(I, Q, pI, pQ, eb, kAtanPolySerial);
 			const int ld = d2i(iir_step(iir, p.iir, (double)dev0));
 			if (bitcnt < 10) {
 				if (ld > dmax)

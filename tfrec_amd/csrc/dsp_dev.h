@@ -2,6 +2,7 @@
 #pragma once
 
 #include "tfrec_dev.h"
+#include "fm_resolve.h"
 
 namespace tfrec {
 
@@ -111,15 +112,14 @@ __device__ __forceinline__ double atan2_int(double cj, double cr, const double *
 // fm_dev, dsp_stuff.cpp:284-292, in the arithmetic of the normative build: (int)(atan2(cj,cr) * (16384/pi)).
 // Exactly representable directions (axes, diagonals, signed zeros) are resolved explicitly with the values
 // glibc returns for them so they do not depend on an approximation's last bits; everywhere else the error of
-// atan2_int can only matter when the product is within ~1e-11 of an integer; such samples are counted
-// (threshold 1e-9) so a run can certify itself (DESIGN.md "fm_dev").
-__device__ __forceinline__ int fm_dev(int ar, int aj, int br, int bj, bool *uncertain, const double *__restrict__ atan_poly)
+// atan2_int (4e-12 in the scaled angle) can only matter when the product is within ~1e-11 of an integer: every
+// sample within 1e-9 is handed to the exact slow path (fm_resolve.h), which decides the truncation as the reference
+// does under a correctly rounded atan2 and logs the sample for the host's libm check at drain time.
+// Returns the scaled angle; true = generic direction within 1e-9 of a truncation boundary.
+__device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out, const double *__restrict__ atan_poly)
 {
-	const double cr = ((double)ar) * br + ((double)aj) * bj;
-	const double cj = ((double)aj) * br - ((double)ar) * bj;
 	const double kPi = 0x1.921fb54442d18p+1, kPi2 = 0x1.921fb54442d18p+0, kPi4 = 0x1.921fb54442d18p-1,
 		     k3Pi4 = 0x1.2d97c7f3321d2p+1;
-	const double kScale = 16384.0 * (1.0 / 0x1.921fb54442d18p+1);
 	double ang;
 	bool generic = false;
 	if (cj == 0.0) {
@@ -133,9 +133,50 @@ __device__ __forceinline__ int fm_dev(int ar, int aj, int br, int bj, bool *unce
 		ang = atan2_int(cj, cr, atan_poly);
 		generic = true;
 	}
-	const double v = ang * kScale;
-	*uncertain = generic && fabs(v - rint(v)) < 1e-9;
-	return d2i(v);
+	const double v = ang * kFmScale;
+	*v_out = v;
+	return generic && fabs(v - rint(v)) < 1e-9;
+}
+
+// double-double sin / cos tables of the slow path (8 KB, touched ~once per 5e8 samples); one copy per translation unit
+static __device__ const double kFmCoarse[129][4] = { TFREC_FM_COARSE_TABLE };
+static __device__ const double kFmFine[128][4] = { TFREC_FM_FINE_TABLE };
+
+// The exact decision for one flagged sample + its log entry.  Not inlined: the fp64 double-double code would otherwise
+// set the register budget of the kernels that call fm_dev for a branch taken once per ~5e8 samples.
+__device__ __noinline__ int fm_dev_slow(double cr, double cj, double v_fast, EventBuf *eb)
+{
+	double margin;
+	const int r = fm_dev_resolve(cr, cj, v_fast, kFmCoarse, kFmFine, &margin);
+	atomicAdd(&eb->uncertain, 1ull);
+	if (margin < kFmUndecidableUlps)
+		atomicAdd(&eb->fm_undecidable, 1u);
+	const uint32_t i = atomicAdd(&eb->fm_logged, 1u);
+	if (i < (uint32_t)kFmLogCap) {
+		eb->fm_log[i].cr = cr;
+		eb->fm_log[i].cj = cj;
+		eb->fm_log[i].result = r;
+		eb->fm_log[i].margin = (float)margin;
+	}
+	return r;
+}
+
+// cr, cj: the cross terms of dsp_stuff.cpp:288-289 (exact integers)
+__device__ __forceinline__ int fm_dev_cross(double cr, double cj, EventBuf *eb, const double *__restrict__ atan_poly)
+{
+	double v;
+	const bool unc = fm_dev_fast(cr, cj, &v, atan_poly);
+	int r = d2i(v);
+	if (__builtin_expect(unc, 0))
+		r = fm_dev_slow(cr, cj, v, eb);
+	return r;
+}
+
+__device__ __forceinline__ int fm_dev(int ar, int aj, int br, int bj, EventBuf *eb, const double *__restrict__ atan_poly)
+{
+	const double cr = ((double)ar) * br + ((double)aj) * bj;
+	const double cj = ((double)aj) * br - ((double)ar) * bj;
+	return fm_dev_cross(cr, cj, eb, atan_poly);
 }
 
 }  // namespace tfrec

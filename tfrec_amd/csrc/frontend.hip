@@ -232,18 +232,13 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 	const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 	int pI = (int)(int16_t)(pw & 0xffff), pQ = (int)pw >> 16;
 	int dv[4];
-	unsigned n_unc = 0;
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
 		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
-		bool unc;
-		dv[o] = fm_dev(I, Q, pI, pQ, &unc, kAtanPolyFront);
-		n_unc += unc ? 1u : 0u;
+		dv[o] = fm_dev(I, Q, pI, pQ, eb, kAtanPolyFront);  // (samples next to a truncation boundary: exact slow path + log)
 		pI = I;
 		pQ = Q;
 	}
-	if (n_unc)
-		atomicAdd(&eb->uncertain, (unsigned long long)n_unc);
 	*reinterpret_cast<uint2 *>(fmdev + (size_t)s * fmdev_stride + m0 + 4 * tid) =
 		make_uint2(((uint32_t)dv[0] & 0xffffu) | ((uint32_t)dv[1] << 16), ((uint32_t)dv[2] & 0xffffu) | ((uint32_t)dv[3] << 16));
 }
@@ -348,6 +343,29 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 }
 
 // after the front end (and the auto-threshold pass, which rewrites the mask)
+// Parity probe (tfrec_amd_fm_dev_probe): the device's fm_dev -- fast path, exact slow path and log -- on arbitrary
+// quadruples (kind 0: int32 ar, aj, br, bj) or cross terms (kind 1: int64 cr, cj).
+__global__ __launch_bounds__(256) void fm_probe_kernel(const int32_t *__restrict__ quads, size_t n, int32_t *__restrict__ out,
+							 EventBuf *__restrict__ eb, int kind)
+{
+	const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (k >= n)
+		return;
+	if (kind == 0) {
+		const int4 q = reinterpret_cast<const int4 *>(quads)[k];
+		out[k] = fm_dev(q.x, q.y, q.z, q.w, eb, kAtanPolyFront);
+	} else {
+		const longlong2 c = reinterpret_cast<const longlong2 *>(quads)[k];
+		out[k] = fm_dev_cross((double)c.x, (double)c.y, eb, kAtanPolyFront);
+	}
+}
+
+hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32_t *out, EventBuf *eb, int kind)
+{
+	hipLaunchKernelGGL(fm_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, quads, n, out, eb, kind);
+	return hipGetLastError();
+}
+
 hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
 			int n_streams, int n_blocks, int wmax)

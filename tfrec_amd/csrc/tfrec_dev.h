@@ -94,10 +94,23 @@ struct FskState {
 	int32_t last_trig;      // last sample with pwr > thresh, relative to the start of the current submit
 };
 
+// fm_dev samples decided by the exact slow path (fm_resolve.h): logged so that the host can check them against its
+// own libm when the batch is drained (capi.hip)
+struct FmLogEntry {
+	double cr, cj;   // the discriminator's cross terms (exact integers)
+	int32_t result;  // what the device returned
+	float margin;    // |theta - rounding midpoint| in ulps of the angle (fm_dev_resolve)
+};
+constexpr int kFmLogCap = 62;
+constexpr double kFmUndecidableUlps = 0.06;  // glibc's atan2 is within 0.55 ulp: closer to a midpoint it may round either way
+
 struct EventBuf {
 	uint32_t count;     // events appended (may exceed capacity -> overflow)
 	uint32_t capacity;
-	unsigned long long uncertain;  // fm_dev results within 1e-9 of a truncation boundary
+	unsigned long long uncertain;  // fm_dev results within 1e-9 of a truncation boundary: decided by the exact slow path
+	uint32_t fm_logged;            // ... of which the first kFmLogCap are in fm_log
+	uint32_t fm_undecidable;       // ... whose margin is below kFmUndecidableUlps
+	FmLogEntry fm_log[kFmLogCap];
 };
 
 // ---- window-parallel pipeline (chains2.hip)
