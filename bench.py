@@ -11,8 +11,15 @@ fixed threshold -t 500, per GPU.  With N GPUs every rank gets its own 1024 strea
 8192 streams, weak scaling, no collective on the data path -- streams are independent).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     dominant kernel vs the HBM roofline (algorithmic bytes = 2 B per complex input sample),
-  "cpu_baseline": the reference CPU path timed on this box's host cores (1 thread) on a bounded sample.
+  "roofline":     dominant kernel vs the HBM roofline (algorithmic bytes = 2 B per complex input sample), the whole
+                  path's fraction, measured HBM traffic (profiles/r02_traffic.json),
+  "cpu_baseline": the reference CPU path timed on this box's host cores (1 thread) on a bounded sample,
+  "h2d_included": the same batches fed from page-locked HOST memory through the submit/drain FIFO (PCIe-inclusive rate;
+                  never `value`),
+  "ms_min/ms_median/ms_max": per-step dispersion (time between consecutive drains inside the timed region).
+Parity gate (before the timed region, on fresh state): EVERY stream of the batch at N=1 (128 spread over the batch per
+rank at N>1) against the CPU oracle; after the timed region the discriminator's self-check counters
+(config.atan_*: samples decided by the exact slow path / differing from this host's libm) -- a mismatch fails the run.
 """
 from __future__ import annotations
 
@@ -123,7 +130,13 @@ def main():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic streams to generate per GPU (0 = auto)")
     ap.add_argument("--cpu-budget", type=float, default=12.0,
                     help="upper bound in seconds for each single-thread leg of the CPU baseline (0 = skip)")
-    ap.add_argument("--parity-streams", type=int, default=4)
+    ap.add_argument("--parity-streams", type=int, default=-1,
+                    help="streams of the first batch checked against the CPU oracle: -1 = all at N=1, 128 spread over the "
+                         "batch per rank at N>1; 0 = none")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="backend of the barrier / scalar reduces at N>1 (the data path has no collective)")
+    ap.add_argument("--same-device", action="store_true", help="tests: every rank uses cuda:0")
+    ap.add_argument("--h2d-steps", type=int, default=4, help="batches of the PCIe-inclusive leg (0 = skip; N=1 only)")
     ap.add_argument("--depth", type=int, default=3, help="batches kept in the submit/drain FIFO (1..3)")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
@@ -140,12 +153,17 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from tfrec_amd import api, synth
+    from tfrec_amd import api, shard, synth
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if a.same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if (world > 1 and a.dist_backend == "nccl") else None  # where the reduced scalars live
 
     n_streams, n_blocks = a.streams, a.blocks
     row = n_blocks * api.BLOCK_BYTES * rate
@@ -160,6 +178,8 @@ def main():
         host = np.stack([synth.gen_stream(1000 + rank, rank * n_streams + s, n_blocks, 0x1F, 256, rate_mult=rate)
                          for s in range(unique)])
     t_gen = time.perf_counter() - t0
+    import zlib
+    input_crc = shard.gather_ints(zlib.crc32(host[0].tobytes()), red_dev)  # every rank generates its own streams
     d_iq = torch.empty((n_streams, row), dtype=torch.uint8, device=dev)
     d_u = torch.from_numpy(host).to(dev)
     for s0 in range(0, n_streams, unique):
@@ -168,30 +188,48 @@ def main():
     del d_u
     torch.cuda.synchronize(dev)
 
-    r = api.Receiver(n_streams, a.types, a.thresh, 0, device=local_rank, max_blocks=n_blocks, timing=True,
+    r = api.Receiver(n_streams, a.types, a.thresh, 0, device=dev_index, max_blocks=n_blocks, timing=True,
                      max_events=max(4096, n_streams * 256), input_10x=a.input_10x)
 
-    # ---- parity gate on this rank's first streams (fresh context state): GPU events == oracle events
+    # ---- parity gate (fresh context state): GPU events of the first batch == oracle events, stream by stream
     parity_ok = None
-    first = None
-    if a.parity_streams > 0:
+    parity_n = 0
+    if a.parity_streams != 0:
         from oracle import oracle as O
         r.submit(d_iq)
         first = r.drain()
-        minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
+        want_n = a.parity_streams if a.parity_streams > 0 else (n_streams if world == 1 else 128)
+        want_n = min(want_n, n_streams)
+        # spread over the batch: first, middle, last (stream s of the batch is distinct stream s % unique)
+        pick = np.unique(np.linspace(0, n_streams - 1, want_n).round().astype(np.int64))
+        parity_n = len(pick)
+        src = np.unique(pick % unique)
+        if rate == 1:
+            orc = dict(zip(src.tolist(), O.process_many(host[src], a.types, a.thresh, 0)))
+        else:
+            orc = {}
+            for u in src.tolist():
+                o = O.Oracle(a.types, a.thresh, 0)
+                o.process_s16(O.decim10(host[u]))
+                orc[u] = np.array([(e[0][0], e[0][2], e[0][3], e[0][4], e[0][1], e[1], np.frombuffer(e[0][5], np.uint8))
+                                   for e in o.events_raw()], dtype=O.ORC_EVENT_DTYPE)
+        minb = np.array([10, 7, 7, 7, 11])
+        gs, gm = api.events_canon(first)
+        bounds = np.searchsorted(gs, np.arange(n_streams + 1))  # the drain orders by (stream, slot, seq)
         parity_ok = True
-        for s in range(min(a.parity_streams, unique)):
-            o = O.Oracle(a.types, a.thresh, 0)
-            if rate == 1:
-                o.process(host[s])
-            else:
-                o.process_s16(O.decim10(host[s]))
-            want = sorted(e for e in o.events() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
-                          and not (e[0] == 4 and e[2] > 60))
-            got = sorted(api.event_tuples(first, s))
-            parity_ok = parity_ok and (got == want)
-        if not parity_ok:
-            print("PARITY FAILURE on rank %d" % rank, file=sys.stderr)
+        for sidx in pick.tolist():
+            e = orc[sidx % unique]
+            # default mode reports the flushes that can print (include/tfrec_amd.h TFREC_AMD_F_ALL_FLUSHES)
+            keep = (e["byte_cnt"] >= minb[e["slot"]]) & ~((e["slot"] == 3) & (e["byte_cnt"] >= 64)) & ~((e["slot"] == 4) & (e["byte_cnt"] > 60))
+            wm = O.canon(e[keep])
+            wm = wm[np.lexsort((wm[:, 1], wm[:, 0]))]
+            g = gm[bounds[sidx]:bounds[sidx + 1]]
+            g = g[np.lexsort((g[:, 1], g[:, 0]))]
+            if g.shape != wm.shape or not np.array_equal(g, wm):
+                parity_ok = False
+                print("PARITY FAILURE on rank %d stream %d" % (rank, sidx), file=sys.stderr)
+                break
+        if shard.sum_over_ranks(0 if parity_ok else 1, red_dev) != 0:
             sys.exit(3)
 
     # Submits and drains form a FIFO (include/tfrec_amd.h, TFREC_AMD_FIFO_DEPTH): up to `depth` batches are queued before
@@ -199,14 +237,16 @@ def main():
     # of consecutive batches overlap.  Exactly n_steps batches are submitted and drained inside run().
     depth = max(1, min(a.depth, api.FIFO_DEPTH))
 
-    def run(n_steps, collect):
+    def run(n_steps, collect, src=None, stamps=None):
         n_ev = 0
         queued = 0
         for k in range(n_steps):
             while queued < n_steps and queued - k < depth:
-                r.submit(d_iq)
+                r.submit(d_iq if src is None else src)
                 queued += 1
             n_ev += len(r.drain())
+            if stamps is not None:
+                stamps.append(time.perf_counter())
             if collect is not None:
                 t = r.timings()  # HIP events recorded on the streams the kernels of the drained batch ran on
                 for kk, v in t.items():
@@ -219,15 +259,48 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    n_events = run(a.steps, kt)
+    stamps = [t0]
+    n_events = run(a.steps, kt, stamps=stamps)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = shard.max_over_ranks(elapsed, red_dev)
+    step_ms = np.diff(np.array(stamps)) * 1e3  # time between consecutive drains of this rank
+    events_all = shard.sum_over_ranks(n_events, red_dev)
+
+    # ---- the discriminator's self check over everything this context processed: samples decided by the
+    # exact slow path, and how many of the logged decisions differ from this host's libm (the reference's arithmetic)
+    fm = r.fm_stats()
+    fm_bad = shard.sum_over_ranks(fm["host_mismatch"], red_dev)
+
+    # ---- PCIe-inclusive leg: the same batch from page-locked host memory through the FIFO (never `value`)
+    h2d = None
+    if a.h2d_steps > 0 and world == 1:
+        try:
+            import ctypes as C
+            L = api.load_library()
+            L.tfrec_amd_host_alloc.restype = C.c_void_p
+            L.tfrec_amd_host_alloc.argtypes = [C.c_size_t]
+            L.tfrec_amd_host_free.argtypes = [C.c_void_p]
+            pin = L.tfrec_amd_host_alloc(n_streams * row)
+            if pin:
+                hbuf = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(n_streams, row))
+                for s0 in range(0, n_streams, unique):
+                    k = min(unique, n_streams - s0)
+                    hbuf[s0:s0 + k] = host[:k]
+                run(2, None, src=hbuf)  # (every submit reads the same pinned batch: nothing writes to it)
+                th = time.perf_counter()
+                run(a.h2d_steps, None, src=hbuf)
+                dt = time.perf_counter() - th
+                h2d = dict(value=round(n_streams * n_blocks * SAMPLES_PER_BLOCK * rate * a.h2d_steps / dt / 1e6, 3),
+                           unit="MSamples/s", ms_per_step=round(dt / a.h2d_steps * 1e3, 3), steps=a.h2d_steps,
+                           pcie_gbs=round(n_streams * row * a.h2d_steps / dt / 1e9, 2),
+                           how="tfrec_amd_submit_host from one page-locked batch, FIFO depth %d" % depth)
+                del hbuf
+                L.tfrec_amd_host_free(pin)
+        except Exception as e:  # the leg is informative: never fail the line for it
+            h2d = dict(error=str(e)[:200])
 
     samples_per_step_gpu = n_streams * n_blocks * SAMPLES_PER_BLOCK * rate  # complex INPUT samples
     total_samples = samples_per_step_gpu * a.steps * world
@@ -243,11 +316,12 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_traffic.json, collected and corrected as
         # MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)
-        traffic = None
+        traffic = traffic_total = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             if (tj.get("streams"), tj.get("blocks"), tj.get("types")) == (n_streams, n_blocks, a.types):
                 traffic = tj["kernels"].get(dom_name, {}).get("hbm_bytes")
+                traffic_total = tj.get("total_hbm_bytes_per_batch")
         except Exception:
             pass
         out = {
@@ -258,6 +332,8 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "ms_min": round(float(step_ms.min()), 4), "ms_median": round(float(np.median(step_ms)), 4),
+            "ms_max": round(float(step_ms.max()), 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -271,13 +347,20 @@ def main():
                             % (n_streams, n_blocks, a.types, a.thresh),
                 "streams_per_gpu": n_streams, "blocks_per_stream": n_blocks, "types_mask": a.types,
                 "thresh": a.thresh, "parallelism": "streams sharded by index, no collective",
-                "events_per_step": n_events // max(1, a.steps), "parity_gate_streams": a.parity_streams,
+                "events_per_step": n_events // max(1, a.steps), "parity_gate_streams": parity_n,
                 "parity_ok": parity_ok, "gen_seconds": round(t_gen, 2),
+                "atan_resolved": fm["resolved"], "atan_host_verified": fm["host_verified"],
+                "atan_host_mismatch": fm_bad, "atan_undecidable": fm["undecidable"],
+                "dist_backend": a.dist_backend if world > 1 else None,
+                "rank_input_crc32": input_crc, "events_all_ranks": events_all,
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "whole_path_frac": round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic_total": traffic_total,
+                "traffic_ratio": round(traffic_total / alg_bytes, 3) if traffic_total else None,
                 "kernels_ms": {k: round(v, 4) for k, v in sorted(kms.items())},
                 "gpu_ms_per_step": round(float(np.mean(kt.get("total_ms", [0.0]))), 4),
                 "speculation_stats": r.stats(),
@@ -286,8 +369,15 @@ def main():
         }
         if a.cpu_budget > 0 and world == 1 and rate == 1:
             out["cpu_baseline"] = cpu_baseline(host[: min(unique, 256)], a.types, a.thresh, a.cpu_budget)
+        if h2d is not None:
+            out["h2d_included"] = h2d
         print(json.dumps(out), flush=True)
     r.close()
+    if fm_bad:
+        print("fm_dev: %d slow-path decisions differ from this host's libm" % fm_bad, file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(4)
     if world > 1:
         dist.destroy_process_group()
 

@@ -80,6 +80,8 @@ def lib():
         L.orc_time_many.restype = C.c_double
         L.orc_time_many.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]
         L.orc_hex.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_process_many.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_num_events.restype = C.c_size_t
         L.orc_num_events.argtypes = [C.c_void_p]
         L.orc_events.restype = C.POINTER(Event)
@@ -191,6 +193,46 @@ class Oracle:
 
     def clear(self):
         self.L.orc_clear_logs(self.h)
+
+
+ORC_EVENT_DTYPE = np.dtype([("slot", "<i4"), ("byte_cnt", "<i4"), ("rssi_db", "<i4"), ("offset", "<i4"),
+                            ("end_sample", "<i8"), ("rssi_raw", "<i8"), ("rdata", "u1", (64,))])
+assert ORC_EVENT_DTYPE.itemsize == 96
+
+
+def usable_threads() -> int:
+    """Host threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def process_many(iq: np.ndarray, types_mask: int = 0x2F, thresh: int = 500, wide: int = 0, cap: int = 1024,
+                 threads: int | None = None):
+    """Fresh receivers over a whole batch iq[n_streams, n_bytes] (OpenMP, one stream per thread at a time).
+    Returns a list with one ORC_EVENT_DTYPE array per stream."""
+    a = np.ascontiguousarray(iq, dtype=np.uint8)
+    n = a.shape[0]
+    out = np.zeros((n, cap), dtype=ORC_EVENT_DTYPE)
+    counts = np.zeros(n, dtype=np.int64)
+    lib().orc_process_many(types_mask, thresh, wide, a.ctypes.data, a.strides[0], a.shape[1], n,
+                           threads or usable_threads(), out.ctypes.data, cap, counts.ctypes.data)
+    assert counts.max(initial=0) <= cap, "orc_process_many: raise cap"
+    return [out[s, : counts[s]] for s in range(n)]
+
+
+def canon(ev: np.ndarray) -> np.ndarray:
+    """Comparable matrix [n, 5 + 64] of ORC_EVENT_DTYPE events: slot, end_sample, byte_cnt, rssi_db, offset, rdata."""
+    m = np.empty((len(ev), 69), dtype=np.int64)
+    for k, f in enumerate(("slot", "end_sample", "byte_cnt", "rssi_db", "offset")):
+        m[:, k] = ev[f]
+    m[:, 5:] = ev["rdata"]
+    return m
 
 
 # ------------------------------------------------------------------ real-reference helpers (this container only)

@@ -1174,6 +1174,24 @@ double orc_time_many(int types_mask, int thresh, int wide, const uint8_t *iq, si
 	return omp_get_wtime() - t0;
 }
 
+/* Batched checker: n_streams independent receivers over `threads` OpenMP threads (stream s = iq + s * stride, nbytes
+ * each, from fresh state); the flush events of stream s land in out[s * cap ...] (the first cap of them), counts[s] =
+ * how many the stream produced.  in16: the input is int16 (I,Q) at 1.536 MS/s (config 5 after orc_decim10). */
+void orc_process_many(int types_mask, int thresh, int wide, const uint8_t *iq, size_t stride, size_t nbytes, int n_streams,
+		      int threads, orc_event_t *out, size_t cap, int64_t *counts)
+{
+	build_tabs();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+	for (int s = 0; s < n_streams; s++) {
+		orc_t *o = orc_create(types_mask, thresh, wide);
+		orc_process(o, iq + (size_t)s * stride, nbytes);
+		const size_t n = o->nev < cap ? o->nev : cap;
+		memcpy(out + (size_t)s * cap, o->ev, n * sizeof(orc_event_t));
+		counts[s] = (int64_t)o->nev;
+		orc_destroy(o);
+	}
+}
+
 /* main.cpp:45-49 with decoder::store_bytes (decoder.cpp:35-40) */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len)
 {

@@ -59,6 +59,11 @@ void orc_decim10(const uint8_t *iq, size_t n_in_complex, int16_t *out);
 double orc_time_many(int types_mask, int thresh, int wide, const uint8_t *iq, size_t stride, size_t nbytes, int n_streams,
 		     int n_jobs, int threads);
 
+/* Batched checker: n_streams fresh receivers over `threads` OpenMP threads; events of stream s -> out[s*cap ..] (first
+ * cap), counts[s] = events the stream produced */
+void orc_process_many(int types_mask, int thresh, int wide, const uint8_t *iq, size_t stride, size_t nbytes, int n_streams,
+		      int threads, orc_event_t *out, size_t cap, int64_t *counts);
+
 /* -X replay (main.cpp:24-53): store_bytes + flush(0) on every registered decoder. */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len);
 

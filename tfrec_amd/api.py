@@ -278,6 +278,22 @@ def fm_dev_probe(records: np.ndarray, device: int = 0, cross: bool = False):
     return out, {n: int(getattr(st, n)) for n, _ in FmStats._fields_[:4]}
 
 
+def events_canon(events: np.ndarray):
+    """Vector form of event_tuples for whole batches: (stream[n], int64 matrix [n, 5 + 64] with the columns slot,
+    end_sample, byte_cnt, rssi_db, offset, rdata) -- the layout of oracle.canon()."""
+    L = load_library()
+    m = np.empty((len(events), 69), dtype=np.int64)
+    m[:, 0] = events["slot"]
+    m[:, 1] = events["end_sample"]
+    m[:, 2] = events["byte_cnt"]
+    slots = events["slot"].tolist()
+    raws = events["rssi_raw"].tolist()
+    m[:, 3] = [L.tfrec_amd_rssi_db(sl, rw) for sl, rw in zip(slots, raws)]
+    m[:, 4] = events["offset"]
+    m[:, 5:] = events["rdata"]
+    return events["stream"].astype(np.int64), m
+
+
 def event_tuples(events: np.ndarray, stream: int | None = None):
     """Canonical comparable form (slot, end_sample, byte_cnt, rssi_db, offset, rdata) of flush events,
     in per-(stream, slot) order -- the same tuple the oracle and the reference harness produce."""

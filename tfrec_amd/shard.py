@@ -32,3 +32,16 @@ def sum_over_ranks(value: int, device=None) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def gather_ints(value: int, device=None) -> list[int]:
+    """One integer per rank, on every rank (a SUM all-reduce of a one-hot vector: works on every backend)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [int(value)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=device if device is not None else "cpu")
+    t[dist.get_rank()] = int(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
