@@ -351,3 +351,22 @@ def test_fm_dev_next_to_truncation_boundaries_equals_the_real_reference(golden_d
     u = np.load(os.path.join(golden_dir, "unit_probes.npz"))
     got, st = api.fm_dev_probe(u["fm_in"])
     assert np.array_equal(got, u["fm_out"][:, 0]) and st["host_mismatch"] == 0
+
+
+@pytest.mark.parametrize("eps", ["1e-3", "3e-2", "0.6"])
+def test_fm_dev_slow_path_through_the_pipeline(eps, monkeypatch):
+    """The exact slow path decides the same integer as the fast path wherever the fast path is certain, so widening
+    the flag threshold (TFREC_AMD_FM_FLAG_EPS) drives it -- the deferred list (1e-3: a few entries per submit; 3e-2:
+    more than the list holds) and the whole-submit rescan (0.6: every sample) -- through the real pipeline with
+    ordinary input: events stay equal to the oracle's, and every logged decision equals this host's libm."""
+    monkeypatch.setenv("TFREC_AMD_FM_FLAG_EPS", eps)
+    n_streams, n_blocks = 4, 16
+    iq = synth.gen_batch(31, 7, n_streams, n_blocks)
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True) as r:
+        for h in range(2):  # two submits: the carried state after a patched submit
+            r.submit(np.ascontiguousarray(iq[:, h * (n_blocks // 2) * 65536:(h + 1) * (n_blocks // 2) * 65536]))
+        ev = np.concatenate([r.drain(), r.drain()])
+        for s in range(n_streams):
+            check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
+        st = r.fm_stats()
+        assert st["resolved"] > 50 and st["host_verified"] > 50 and st["host_mismatch"] == 0

@@ -1740,6 +1740,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 256 B, used by the decoder tail
 	__shared__ double2 pb[64];
 	__shared__ double yl[64];
+#ifdef TFREC_AMD_WHB_PRIO
+	__builtin_amdgcn_s_setprio(TFREC_AMD_WHB_PRIO);
+#endif
 	constexpr int kStep = 64;  // samples per iteration: one per lane
 	const int ln = threadIdx.x;
 	const int s = blockIdx.x;  // one wave per stream
@@ -2796,7 +2799,7 @@ __global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restr
 // ------------------------------------------------------------------------------------------------ launch
 hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			int n_streams, int n_blocks, int wmax);
+			int n_streams, int n_blocks, int wmax, double flag_eps);
 
 hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
@@ -2933,7 +2936,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		if (P.fmdev_wmax > 0) {
 			mark(24, P.k2);
 			TRY(launch_fmdev(P.k2, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,
-					 n_blocks, P.fmdev_wmax));
+					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));
 			mark(25, P.k2);
 		}
 		mark(1, P.k2);

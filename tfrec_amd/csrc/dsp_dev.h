@@ -116,7 +116,8 @@ __device__ __forceinline__ double atan2_int(double cj, double cr, const double *
 // sample within 1e-9 is handed to the exact slow path (fm_resolve.h), which decides the truncation as the reference
 // does under a correctly rounded atan2 and logs the sample for the host's libm check at drain time.
 // Returns the scaled angle; true = generic direction within 1e-9 of a truncation boundary.
-__device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out, const double *__restrict__ atan_poly)
+__device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out, const double *__restrict__ atan_poly,
+					    double flag_eps = 1e-9)
 {
 	const double kPi = 0x1.921fb54442d18p+1, kPi2 = 0x1.921fb54442d18p+0, kPi4 = 0x1.921fb54442d18p-1,
 		     k3Pi4 = 0x1.2d97c7f3321d2p+1;
@@ -135,7 +136,7 @@ __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out,
 	}
 	const double v = ang * kFmScale;
 	*v_out = v;
-	return generic && fabs(v - rint(v)) < 1e-9;
+	return generic && fabs(v - rint(v)) < flag_eps;
 }
 
 // double-double sin / cos tables of the slow path (8 KB, touched ~once per 5e8 samples); one copy per translation unit

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							      const unsigned long long *__restrict__ mask, size_t mask_stride,
 							      const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
-							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax)
+							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax, double flag_eps)
 {
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
@@ -235,7 +235,15 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
 		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
-		dv[o] = fm_dev(I, Q, pI, pQ, eb, kAtanPolyFront);  // (samples next to a truncation boundary: exact slow path + log)
+		double v;
+		const bool unc = fm_dev_fast(((double)I) * pI + ((double)Q) * pQ, ((double)Q) * pI - ((double)I) * pQ, &v, kAtanPolyFront,
+					     flag_eps);
+		dv[o] = d2i(v);
+		if (__builtin_expect(unc, 0)) {  // next to a truncation boundary (~2e-9 of the samples): fm_resolve_kernel decides it
+			const uint32_t i = atomicAdd(&eb->fm_pending, 1u);
+			if (i < (uint32_t)kFmListCap)
+				eb->fm_list[i] = ((unsigned long long)(uint32_t)s << 32) | (uint32_t)(m0 + 4 * tid + o);
+		}
 		pI = I;
 		pQ = Q;
 	}
@@ -366,14 +374,43 @@ hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32
 	return hipGetLastError();
 }
 
+// The samples fmdev_kernel flagged, decided by the exact slow path (fm_resolve.h) and logged for the host's check.
+// Launched behind every fmdev_kernel; normally nothing is pending and every workgroup returns at once.
+__global__ __launch_bounds__(256) void fm_resolve_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+							   const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
+							   size_t fmdev_stride, EventBuf *__restrict__ eb, int n_streams, int m_total)
+{
+	const uint32_t pending = eb->fm_pending;
+	if (pending == 0)
+		return;
+	const size_t nthreads = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+	auto one = [&](int s, int m) {
+		const uint32_t *drow = dec + (size_t)s * dec_stride;
+		const uint32_t w = drow[m], pw = m > 0 ? drow[m - 1] : prevdec[s];
+		fmdev[(size_t)s * fmdev_stride + m] = (int16_t)fm_dev((int)(int16_t)(w & 0xffff), (int)w >> 16, (int)(int16_t)(pw & 0xffff),
+								    (int)pw >> 16, eb, kAtanPolyFront);
+	};
+	if (pending <= (uint32_t)kFmListCap) {
+		for (size_t i = t0; i < pending; i += nthreads) {
+			const unsigned long long e = eb->fm_list[i];
+			one((int)(e >> 32), (int)(uint32_t)e);
+		}
+	} else {  // more flagged samples than the list holds (a periodic input can repeat one direction): redo the whole submit
+		for (size_t i = t0; i < (size_t)n_streams * m_total; i += nthreads)
+			one((int)(i / m_total), (int)(i % m_total));
+	}
+}
+
 hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			int n_streams, int n_blocks, int wmax)
+			int n_streams, int n_blocks, int wmax, double flag_eps)
 {
 	const int m_total = n_blocks * kBlockDec;
 	dim3 grid(m_total / kTileDec, n_streams);
 	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFrontThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
-			   fmdev_stride, eb, wmax);
+			   fmdev_stride, eb, wmax, flag_eps);
+	hipLaunchKernelGGL(fm_resolve_kernel, dim3(128), dim3(256), 0, st, dec, dec_stride, prevdec, fmdev, fmdev_stride, eb,
+			   n_streams, m_total);
 	return hipGetLastError();
 }
 

@@ -111,7 +111,14 @@ struct EventBuf {
 	uint32_t fm_logged;            // ... of which the first kFmLogCap are in fm_log
 	uint32_t fm_undecidable;       // ... whose margin is below kFmUndecidableUlps
 	FmLogEntry fm_log[kFmLogCap];
+	// fmdev_kernel defers its flagged samples to fm_resolve_kernel (the slow path as a call inside the hot kernel
+	// doubled its registers: 0.8 ms per batch): (stream << 32 | sample) of every flagged sample; more than
+	// kFmListCap pending = the resolve kernel rescans the whole submit instead
+	uint32_t fm_pending;
+	uint32_t pad_;
+	unsigned long long fm_list[256];
 };
+constexpr int kFmListCap = 256;
 
 // ---- window-parallel pipeline (chains2.hip)
 
@@ -224,6 +231,7 @@ struct PipeCtl {
 	// the FM discriminator pass, when it runs at the head of stage A of the TFA_2 family (k2) instead of behind the
 	// front end (its only consumer is that stage): wmax > 0
 	int fmdev_wmax;
+	double fm_flag_eps;  // distance of the scaled angle to an integer below which a sample goes to the exact slow path
 	int16_t *fmdev_out;
 	const uint32_t *prevdec;
 };
