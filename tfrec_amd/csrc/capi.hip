@@ -18,7 +18,7 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 			   bool in16);
 hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			size_t mask_stride, const uint32_t *prevdec, int16_t *fmdev, size_t fmdev_stride, EventBuf *eb,
-			int n_streams, int n_blocks, int wmax);
+			int n_streams, int n_blocks, int wmax, double flag_eps);
 hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
 			   size_t mask_stride, const int16_t *fmdev, size_t fmdev_stride, int n_streams, int n_blocks,
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
@@ -124,6 +124,10 @@ struct tfrec_amd_ctx {
 	// fm_dev samples decided by the exact slow path: all / checked against this host's libm at drain / differing from
 	// it / closer to a rounding midpoint than glibc's error bound
 	FmTotals fm;
+	// fm_dev samples closer than this to a truncation boundary take the exact slow path.  1e-9 = 250x the fast path's
+	// error bound; TFREC_AMD_FM_FLAG_EPS (tests) widens it to drive the slow path -- exact for any value -- through the
+	// pipeline with ordinary input: 1e-3 fills the deferred list, 0.6 overflows it (every sample: the rescan path)
+	double fm_flag_eps = 1e-9;
 };
 
 // ---- biquad coefficients (iir2::set, dsp_stuff.cpp:36-45) in the arithmetic of the reference's normative
@@ -314,6 +318,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	if (!c)
 		return TFREC_AMD_E_NOMEM;
 	c->cfg = *cfg;
+	if (const char *fe = getenv("TFREC_AMD_FM_FLAG_EPS"))
+		c->fm_flag_eps = std::max(1e-9, atof(fe));
 	memset(&c->launch, 0, sizeof(c->launch));
 	memset(&c->win, 0, sizeof(c->win));
 
@@ -631,7 +637,8 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	const bool fmdev_k2 = c->need_fmdev && c->fmdev_k2 && !(c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS);
 	if (c->need_fmdev && !fmdev_k2)  // FM discriminator of the samples near trigger windows (after the mask is final)
 		HIPCHK(launch_fmdev(fs, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_prevdec[set],
-				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax));
+				    c->d_fmdev[set], c->dec_stride, c->d_eb[set], c->cfg.n_streams, n_blocks, c->wmax,
+				    c->fm_flag_eps));
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][1], fs));
 	HIPCHK(hipEventRecord(c->ev_front[set], fs));
@@ -661,6 +668,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 			P.done[k] = c->done[set][k];
 		P.tev = (timing && c->tev[set][0]) ? c->tev[set] : nullptr;
 		P.fmdev_wmax = fmdev_k2 ? c->wmax : 0;
+		P.fm_flag_eps = c->fm_flag_eps;
 		P.fmdev_out = c->d_fmdev[set];
 		P.prevdec = c->d_prevdec[set];
 		HIPCHK(launch_pipeline(P, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set], c->dec_stride,
