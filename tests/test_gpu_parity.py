@@ -353,11 +353,11 @@ def test_fm_dev_next_to_truncation_boundaries_equals_the_real_reference(golden_d
     assert np.array_equal(got, u["fm_out"][:, 0]) and st["host_mismatch"] == 0
 
 
-@pytest.mark.parametrize("eps", ["1e-3", "3e-2", "0.6"])
+@pytest.mark.parametrize("eps", ["1e-4", "1e-3", "0.6"])
 def test_fm_dev_slow_path_through_the_pipeline(eps, monkeypatch):
     """The exact slow path decides the same integer as the fast path wherever the fast path is certain, so widening
-    the flag threshold (TFREC_AMD_FM_FLAG_EPS) drives it -- the deferred list (1e-3: a few entries per submit; 3e-2:
-    more than the list holds) and the whole-submit rescan (0.6: every sample) -- through the real pipeline with
+    the flag threshold (TFREC_AMD_FM_FLAG_EPS) drives it -- the deferred list (1e-4: ~40 entries per submit), its
+    overflow (1e-3: more than the list holds) and the whole-submit rescan (0.6: every sample) -- through the real pipeline with
     ordinary input: events stay equal to the oracle's, and every logged decision equals this host's libm."""
     monkeypatch.setenv("TFREC_AMD_FM_FLAG_EPS", eps)
     n_streams, n_blocks = 4, 16
@@ -369,4 +369,5 @@ def test_fm_dev_slow_path_through_the_pipeline(eps, monkeypatch):
         for s in range(n_streams):
             check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
         st = r.fm_stats()
-        assert st["resolved"] > 50 and st["host_verified"] > 50 and st["host_mismatch"] == 0
+        assert st["resolved"] > 30 and st["host_verified"] > 30 and st["host_mismatch"] == 0
+        assert st["undecidable"] == 0

@@ -85,8 +85,10 @@ TFREC_HD int fm_dev_resolve(double cr, double cj, double v_fast, const double (*
 	const double y = fabs(cj), x = cr;
 	const int sgn = cj < 0.0 ? -1 : 1;
 	const int k = (int)rint(fabs(v_fast));
-	if (k < 1 || k > 16383) {  // not reachable with integer cross terms below 2^32 (the angle stays 4e-10 rad off the axis)
-		*margin_ulps = 0.0;
+	if (k < 1 || k > 16383) {
+		// |v| < 0.5 or >= 16383.5: the truncation is 0 / +-16383 whatever the last bits are (integer cross terms below
+		// 2^32 keep a generic direction 4e-10 rad = 2e-6 in v off the axes).  Only reached with a widened flag threshold.
+		*margin_ulps = 1e30;
 		return (int)v_fast;
 	}
 	const double kd = (double)k;

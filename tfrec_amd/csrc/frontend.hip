@@ -378,26 +378,30 @@ hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32
 // Launched behind every fmdev_kernel; normally nothing is pending and every workgroup returns at once.
 __global__ __launch_bounds__(256) void fm_resolve_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							   const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
-							   size_t fmdev_stride, EventBuf *__restrict__ eb, int n_streams, int m_total)
+							   size_t fmdev_stride, EventBuf *__restrict__ eb, int n_streams, int m_total,
+							   double flag_eps)
 {
 	const uint32_t pending = eb->fm_pending;
 	if (pending == 0)
 		return;
 	const size_t nthreads = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-	auto one = [&](int s, int m) {
+	auto one = [&](int s, int m, bool listed) {
 		const uint32_t *drow = dec + (size_t)s * dec_stride;
 		const uint32_t w = drow[m], pw = m > 0 ? drow[m - 1] : prevdec[s];
-		fmdev[(size_t)s * fmdev_stride + m] = (int16_t)fm_dev((int)(int16_t)(w & 0xffff), (int)w >> 16, (int)(int16_t)(pw & 0xffff),
-								    (int)pw >> 16, eb, kAtanPolyFront);
+		const int I = (int)(int16_t)(w & 0xffff), Q = (int)w >> 16, pI = (int)(int16_t)(pw & 0xffff), pQ = (int)pw >> 16;
+		const double cr = ((double)I) * pI + ((double)Q) * pQ, cj = ((double)Q) * pI - ((double)I) * pQ;
+		double v;
+		const bool unc = fm_dev_fast(cr, cj, &v, kAtanPolyFront, flag_eps);
+		fmdev[(size_t)s * fmdev_stride + m] = (int16_t)((listed || unc) ? fm_dev_slow(cr, cj, v, eb) : d2i(v));
 	};
 	if (pending <= (uint32_t)kFmListCap) {
 		for (size_t i = t0; i < pending; i += nthreads) {
 			const unsigned long long e = eb->fm_list[i];
-			one((int)(e >> 32), (int)(uint32_t)e);
+			one((int)(e >> 32), (int)(uint32_t)e, true);
 		}
 	} else {  // more flagged samples than the list holds (a periodic input can repeat one direction): redo the whole submit
 		for (size_t i = t0; i < (size_t)n_streams * m_total; i += nthreads)
-			one((int)(i / m_total), (int)(i % m_total));
+			one((int)(i / m_total), (int)(i % m_total), false);
 	}
 }
 
@@ -410,7 +414,7 @@ hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, 
 	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFrontThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
 			   fmdev_stride, eb, wmax, flag_eps);
 	hipLaunchKernelGGL(fm_resolve_kernel, dim3(128), dim3(256), 0, st, dec, dec_stride, prevdec, fmdev, fmdev_stride, eb,
-			   n_streams, m_total);
+			   n_streams, m_total, flag_eps);
 	return hipGetLastError();
 }
 
