@@ -6,8 +6,8 @@ name=$1; shift
 mkdir -p $R/tfrec_amd/ab /tmp/ab_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
 for f in frontend chains chains2 capi; do
-	/opt/rocm/bin/hipcc $FLAGS "$@" -c $R/tfrec_amd/csrc/$f.hip -o /tmp/ab_$name/$f.o &
+	/opt/rocm/bin/hipcc $FLAGS "$@" -c ${SRC:-$R}/tfrec_amd/csrc/$f.hip -o /tmp/ab_$name/$f.o &
 done
-wait
+wait || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tfrec_amd/ab/$name.so /tmp/ab_$name/*.o
 echo built $R/tfrec_amd/ab/$name.so

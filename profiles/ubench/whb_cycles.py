@@ -27,8 +27,13 @@ with api.Receiver(ns, mask, 500, 0, max_blocks=nb, max_events=1 << 20) as r:
     span = [int(st.biquad_unconverged), int(st.biquad_serial), int(st.tfa2_resliced)]
 steps, usteps = raw[0] >> 32, raw[0] & 0xffffffff
 print("per stream and submit: steps %.0f, with recurrence %.0f" % (steps / ns / nsub, usteps / ns / nsub))
-print("cycles per stream and submit: recurrence %.2fM, candidate walk %.2fM, whole demodulator %.2fM" % tuple(x / ns / nsub / 1e6 for x in raw[1:4]))
+print("cycles per stream and submit: recurrence %.2fM, whole demodulator %.2fM; wall %.3f ms per stream -> shader clock %.2f GHz" % (
+    raw[1] / ns / nsub / 1e6, raw[3] / ns / nsub / 1e6, raw[2] / ns / nsub / 1e5, raw[3] / max(raw[2], 1) / 10.0))
 print("recurrence: %.0f cycles per step = %.1f per sample" % (raw[1] / max(usteps, 1), raw[1] / max(usteps, 1) / 64))
 if len(sys.argv) > 3 and sys.argv[3] == "span":  # library built with -DTFREC_AMD_PROFILE_WHB_SPAN as well
     first = (~span[0]) & 0xFFFFFFFFFFFFFFFF
-    print("sixth submit: workgroups start over %.3f ms, kernel first start -> last end %.3f ms" % ((span[1] - first) / 1e5, (span[2] - first) / 1e5))
+    mean = (int(st.biquad_segments) - ns * (first & 0xffffffffff)) / ns  # (low 40 bits summed)
+    print("sixth submit: workgroups start over %.3f ms (mean start +%.3f ms), kernel first start -> last end %.3f ms" % (
+        (span[1] - first) / 1e5, mean / 1e5, (span[2] - first) / 1e5))
+    print("slowest stream of that submit: %.2fM cycles, %d steps" % ((raw[1] >> 24) / 1e6, raw[1] & 0xffffff))
+    print("streams by cycles per step: <2500: %d, <3000: %d, <3500: %d, <4500: %d, more: %d" % tuple((raw[2] >> (12 * b)) & 0xfff for b in range(5)))

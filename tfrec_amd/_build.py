@@ -34,7 +34,7 @@ def hipcc() -> str:
 def build_device_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into tfrec_amd/libtfrec_amd.so."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("tfrec_dev.h", "dsp_dev.h", "decoder_dev.h")] + [ os.path.join(ROOT, "include", "tfrec_amd.h"), __file__]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("tfrec_dev.h", "dsp_dev.h", "decoder_dev.h", "fm_resolve.h", "fm_resolve_tables.h", "whb_chain_asm.h")] + [ os.path.join(ROOT, "include", "tfrec_amd.h"), __file__]
     if force or _stale(LIB_SO, deps):
         objs = []
         for s in srcs:

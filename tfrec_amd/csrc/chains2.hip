@@ -35,6 +35,7 @@
 #include <algorithm>
 
 #include "decoder_dev.h"
+#include "whb_chain_asm.h"
 
 namespace tfrec {
 
@@ -1547,10 +1548,9 @@ __device__ __forceinline__ void whb_store_bit_m(Dec &d, int bit, unsigned long l
 		wmask |= 7ull;
 	}
 	if (d.sr_cnt == 0) {
-		if (d.byte_cnt < 256) {
+		if (d.byte_cnt < 64) {  // only rdata[0 .. 64) is ever looked at (flush reads r[plen + 3], plen <= 60: whb.cpp:484-510)
 			d.rdata[d.byte_cnt] = (d.sr >> 24) & 0xff;
-			if (d.byte_cnt < 64)
-				wmask |= 1ull << d.byte_cnt;
+			wmask |= 1ull << d.byte_cnt;
 		}
 		d.byte_cnt++;
 	}
@@ -1710,775 +1710,433 @@ __device__ __forceinline__ void whb_commit_stream(int s, int n_streams, int n_bl
 
 
 // ------------------------------------------------------------------------------------------------ K4' WHB stage 2
-// whb_demod::demod after the first low-pass (whb.cpp:653-703), wave-cooperative: 32 lanes per stream, two streams
-// per wave.  With only ~1000 streams a lane-per-stream kernel is bound by the issue rate of a lone wave (one
-// instruction per ~4.5 cycles, whatever the number of active lanes), so the per-sample instruction count of the
-// SERIAL part is what matters.  Per 32-sample slot of stage-1 output the lanes therefore split the work:
-//   (1) lane n owns sample n: it forms the feed-forward half of the decision-level biquad for its sample,
-//       P(n) = fl(b0*dn + b1*dn1) and B2(n) = fl(b2*dn2) (exactly the two sub-sums of iir_step), into LDS;
-//   (2) every lane runs the 32-step feedback recurrence y = ((B2 + a1*y1) + P) + a2*y2 redundantly (5 fp64
-//       operations + one broadcast LDS read + one LDS write per sample -- the only serial work), only while the
-//       decoder is unsynced (whb.cpp:653);
-//   (3) lane n reads back y(n) -> avg_of(n), tests "local minimum below average" (whb.cpp:662-663), and a ballot
-//       gives the slot's candidate mask;
-//   (4) the (sparse) candidates that pass the 3/4-bit spacing rule (:664) are turned into runs "0,1,1,..";
-//       has_sync() (:653/:677/:693) is tracked by evaluating the decoder's sync word for all positions of a
-//       run at once, one position per lane.  Since psk/nrzs/lfsr/sr are GF(2)-linear in the emitted bits
-//       (nrzs(t) = bit(t) ^ K, out(t) = nrzs(t) ^ nrzs(t-12) ^ nrzs(t-17)), this needs no per-bit loop.
-// When the decoder locks at sample k of a slot the recurrence output y(0..k) is already in LDS: the filter
-// state is taken at k and the candidates after k are re-tested against the frozen average -- no rewind.
-// The runs (one uint16 length per accepted candidate) go to the window's bit region; commit_kernel replays
-// them through whb_decoder::store_bit and reports the flush.  The RSSI sum of a synced interval (:678) is an
-// exact integer, so it is taken as a difference of the power prefix K3a stored per slot.
+// whb_demod::demod after the first low-pass (whb.cpp:653-703): ONE WAVE PER STREAM, 64 samples per step.
+//
+// The decision-level average (iir_avg, whb.cpp:654) is a non-contracting biquad that only runs while the decoder is
+// unsynced -- it can neither be speculated nor separated from the bit decisions, so a stream is one serial chain of
+// ~120 k recurrence steps per batch, and with ~1000 streams there is one such wave per SIMD: the kernel's duration is
+// the number of instructions ONE wave issues (a lone wave issues one instruction per 4-8 cycles whatever the lane
+// count).  Everything here is arranged to keep that count down:
+//   * windows are the outer loop, the steps of a window the inner one (contiguous addresses, two loads in flight);
+//   * per step, lane n owns sample n: neighbours by DPP wave shifts, the feed-forward terms of the biquad in the
+//     3-multiply form of iir_step_t() (b1 = 2 b0, b2 = b0: P = fma(2, t1, t0), B2 = t2, t = fl((b0/2) * dev));
+//   * the 64-step feedback recurrence y = ((B2 + a1*y1) + P) + a2*y2 runs on all lanes redundantly, fully unrolled
+//     behind register-resident feed-forward pairs (5 fp64 operations + 1.5 LDS instructions per sample: the serial
+//     floor); lane n reads y(n) back, "dev < avg_of && dev > last_dev" (whb.cpp:662-663) is one ballot;
+//   * the accepted candidates (spacing rule :664; about one per step) emit runs "0,1,1,.." whose lengths are
+//     collected lane-per-entry in a register and stored 64 at a time; has_sync() is tracked without a per-bit loop:
+//     store_bit leaves last_psk == psk, hence nrzs(t) = bit(t) ^ K and the descrambled bit is
+//     nrzs(t) ^ nrzs(t-12) ^ nrzs(t-17) (whb.cpp:568-580) -- GF(2)-linear, so the 32-bit sync compare is evaluated for
+//     all positions of a run at once, one position per lane;
+//   * once the decoder has locked (until the window's flush) a step is only the candidate test against the frozen
+//     average plus a per-lane power sum (whb.cpp:677-678: exact integers, reduced once per window).
+// When the decoder locks at sample k of a step, y(0..k) is already in LDS: the filter state is taken at k and the
+// candidates after k are re-tested against the frozen average -- no rewind.
+// The decoder stages (whb_decode_window, whb_commit_stream) run in the tail, by the same wave.
 constexpr uint32_t kWhbSyncRev = 0xd2b42bd4u;  // bit-reversed 0x2bd42d4b (whb.cpp:582): newest bit at the LSB
+
+__device__ __forceinline__ int wave_shr1(int v)  // lane n <- lane n-1 (lane 0: 0)
+{
+	return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
+}
+// out[j] = row j of v in all four rows: lane 16r + i receives v of lane 16j + i (v_permlane16_swap, v_permlane32_swap)
+__device__ __forceinline__ void rows_replicate(int v, int (&out)[4])
+{
+	const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);        // (R0 R0 R2 R2), (R1 R1 R3 R3)
+	const auto e = __builtin_amdgcn_permlane32_swap(r[0], r[0], false, false);  // (R0 x4), (R2 x4)
+	const auto o = __builtin_amdgcn_permlane32_swap(r[1], r[1], false, false);  // (R1 x4), (R3 x4)
+	out[0] = e[0];
+	out[1] = o[0];
+	out[2] = e[1];
+	out[3] = o[1];
+}
+__device__ __forceinline__ void rows_replicate(double v, double (&out)[4])
+{
+	int lo[4], hi[4];
+	rows_replicate(__double2loint(v), lo);
+	rows_replicate(__double2hiint(v), hi);
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		out[j] = __hiloint2double(hi[j], lo[j]);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)  // wave-uniform lane
+{
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 
 __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 						       long long sample_base, ChainLaunch L, int a, WinTables T,
 						       tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 256 B, used by the decoder tail
-	__shared__ double2 pb[64];
-	__shared__ double yl[64];
+	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 64 B, used by the decoder tail
 #ifdef TFREC_AMD_WHB_PRIO
 	__builtin_amdgcn_s_setprio(TFREC_AMD_WHB_PRIO);
+#endif
+	// One of these waves per SIMD, never two: the kernel claims 264 of a SIMD's 512 registers (256 + 8 accumulation
+	// registers it never touches).  Its one-wave workgroups are dispatched while the other chains' kernels fill the chip
+	// and land wherever a wave slot is free; two of them on one SIMD share its VALU (the recurrence alone wants 3/4 of
+	// it) and run at half speed, and the kernel ends with its slowest stream: a third of the streams ran doubled up,
+	// the slowest took 2.2x the average (profiles/ubench/whb_cycles.py span); with the claim 8.7 -> 6.7 ms in the batch.
+#ifndef TFREC_AMD_WHB_THIN
+	asm volatile("" ::: "v255", "a7");
 #endif
 	constexpr int kStep = 64;  // samples per iteration: one per lane
 	const int ln = threadIdx.x;
 	const int s = blockIdx.x;  // one wave per stream
-	const ChainParams &p = L.params[a];
-	ChainState &st = L.states[a][s];
 	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
-	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const int32_t *dvrow = dev32 + (size_t)s * T.slots * 32;
-	const BiquadCoef cavg = p.iir_avg;
-	const double spb = p.spb;
-	const double thr = 3 * spb / 4;        // whb.cpp:664
-	const int tmin = (int)floor(thr) + 1;  // smallest integer tdiff with tdiff > thr
-	// (int)((tdiff + spb/2) / spb) is an exact shift when spb is a power of two (the reference's WHB: 64.0)
-	const int spb_i = (int)spb;
-	const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
-	const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
-	// ---- per-stream state, wave-uniform
-	Biquad f = st.iir_avg;
-	int avg_of = st.avg_of, last_dev = st.last_dev;
-	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
-	// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
-	// additions are exact in any order: the lanes add their samples' power in integers.
-	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
-	unsigned long long rssi_acc = 0;       // ... and in this submit
-	int synced = st.synced;
-	// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
-	// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
-	uint32_t srr = __brev(st.sr);          // whb_decoder::sr, newest bit at the LSB
-	uint32_t nh = st.lfsr;                 // history of nrzs, newest at the LSB (whb.cpp:579)
-	const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
-	// sr_cnt / byte_cnt while the decoder has not locked since its last flush (they only matter before a stream's
-	// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
-	int sc = st.sr_cnt, bc = st.byte_cnt;
 	const int count = T.count[c];
-	const bool cont = T.cont[c] != 0;
 #ifdef TFREC_AMD_PROFILE_WHB
-	long long pf_rec = 0, pf_steps = 0, pf_usteps = 0, pf_cand = 0, pf_t0 = __builtin_readcyclecounter();
+	long long pf_rec = 0, pf_steps = 0, pf_usteps = 0, pf_t0 = __builtin_readcyclecounter();
+	long long pf_top = 0, pf_walk = 0, pf_tail = 0, pf_mark = 0;
 	const long long pf_w0 = wall_clock64();  // 100 MHz
 #endif
-
-	auto wave_sum = [&](unsigned long long v) -> unsigned long long {
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1)
-			v += __shfl_xor(v, o, 64);
-		return v;
-	};
-	// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
-	auto feed = [&](uint32_t e, int len) -> bool {
-		const uint32_t emask = len >= 32 ? ~0u : (1u << len) - 1u;
-		const uint32_t nrun = __brev((e ^ kmask) & emask) >> (32 - len);           // nrzs of the run, newest at the LSB
-		const unsigned long long hn = ((unsigned long long)nh << len) | nrun;
-		const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;    // descrambled bits, whb.cpp:578
-		const unsigned long long sv = ((unsigned long long)srr << len) | orun;
-		const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
-		nh = (uint32_t)hn;
-		srr = (uint32_t)sv;
-		return __ballot(hit) != 0ull;
-	};
-	// sr_cnt / byte_cnt over `len` bits without a sync word (whb.cpp:590-596)
-	auto count_bits = [&](int len) {
-		if (sc >= 0) {
-			const int i0 = (8 - sc) & 7;  // first bit of the run that finds sr_cnt == 0
-			bc += i0 < len ? (len - 1 - i0) / 8 + 1 : 0;
-			sc = (sc + len) & 7;
-		}
-	};
-	struct Win {
-		int og, n, nch, slot0, closed;
-	};
-	auto read_win = [&](int jj) -> Win {
-		Win r;
-		const int jc = jj < count ? jj : (count > 0 ? count - 1 : 0);
-		r.og = T.open[(size_t)c * T.cap + jc];
-		const int close = T.close[(size_t)c * T.cap + jc];
-		r.closed = close < M;
-		r.n = (r.closed ? close : M - 1) - r.og + 1;
-		r.nch = (r.n + kStep - 1) / kStep;
-		r.slot0 = win_slot0(r.og, jc);
-		return r;
-	};
-	// the lane's stage-1 output and the two before it (the first lanes take theirs from the carried state)
-	struct Dev3 {
-		int d0, d1, d2;
-	};
-	auto load_dev = [&](int slot0, int i) -> Dev3 {
-		const int idx = slot0 * 32 + kStep * i + ln;
-		Dev3 r;
-		r.d0 = dvrow[idx];
-		r.d1 = dvrow[idx > 0 ? idx - 1 : 0];
-		r.d2 = dvrow[idx > 1 ? idx - 2 : 0];
-		return r;
-	};
 	if (count > 0) {
-		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);  // current, next, next-but-one window
-		int j = 0, i = 0, nent = 0;
-		// the stage-1 outputs of step k + `ahead`, looking across the window boundaries known here (cw, nw, nnw); past
-		// the chain's end any valid slot is read and never used
-		auto load_ahead = [&](int ahead) -> Dev3 {
-			int ii = i + ahead;
-			if (ii < cw.nch)
-				return load_dev(cw.slot0, ii);
-			ii -= cw.nch;
-			if (j + 1 < count) {
-				if (ii < nw.nch)
-					return load_dev(nw.slot0, ii);
-				ii -= nw.nch;
-				if (j + 2 < count && ii < nnw.nch)
-					return load_dev(nnw.slot0, ii);
-			}
-			return load_dev(cw.slot0, 0);
+		const uint32_t *drow = dec + (size_t)s * dec_stride;
+		const int32_t *dvrow = dev32 + (size_t)s * T.slots * 32;
+		const ChainParams &p = L.params[a];
+		ChainState &st = L.states[a][s];
+		const double a1 = p.iir_avg.a1, a2 = p.iir_avg.a2;
+		const double bh = 0.5 * p.iir_avg.b0;  // t = fl(b0 * (0.5 * dev)) = fl((b0 / 2) * dev): scaling by two is exact
+		const double spb = p.spb;
+		const int tmin = (int)floor(3 * spb / 4) + 1;  // smallest integer tdiff with tdiff > 3*spb/4 (whb.cpp:664)
+		// (int)((tdiff + spb/2) / spb) is an exact shift when spb is a power of two (the reference's WHB: 64.0)
+		const int spb_i = (int)spb;
+		const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
+		const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
+		// ---- per-stream state, wave-uniform
+		double y1 = st.iir_avg.yn, y2 = st.iir_avg.yn1;  // iir_avg: its last two outputs ...
+		// ... and its last two inputs: 0.5 * (a stage-1 output) each, carried as the integers
+		int fd1 = (int)(2.0 * st.iir_avg.dn1), fd2 = (int)(2.0 * st.iir_avg.dn2);
+		int avg_of = st.avg_of, last_dev = st.last_dev;
+		long long step0 = (long long)st.step;               // samples since the window opened, at the window's first sample here
+		long long since = step0 - (long long)st.last_peak;  // ... since the last accepted candidate, at the step's first sample
+		// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
+		// additions are exact in any order: every lane adds its samples' power, the wave sums once per window.
+		double rssi_d = st.rssi_d;    // rssi collected in earlier submits of a still-open window
+		unsigned long long racc = 0;  // ... and in this submit (per lane)
+		int synced = st.synced;
+		// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
+		// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
+		uint32_t srr = __brev(st.sr);  // whb_decoder::sr, newest bit at the LSB
+		uint32_t nh = st.lfsr;         // history of nrzs, newest at the LSB (whb.cpp:579)
+		const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
+		// sr_cnt / byte_cnt while the decoder has not locked since its last flush (they only matter before a stream's
+		// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
+		int sc = st.sr_cnt, bc = st.byte_cnt;
+		const bool cont = T.cont[c] != 0;
+
+		// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
+		auto feed = [&](uint32_t e, int len) -> bool {
+			const uint32_t emask = len >= 32 ? ~0u : (1u << len) - 1u;
+			const uint32_t nrun = __brev((e ^ kmask) & emask) >> (32 - len);         // nrzs of the run, newest at the LSB
+			const unsigned long long hn = ((unsigned long long)nh << len) | nrun;
+			const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;  // descrambled bits, whb.cpp:578
+			const unsigned long long sv = ((unsigned long long)srr << len) | orun;
+			const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
+			nh = (uint32_t)hn;
+			srr = (uint32_t)sv;
+			return __ballot(hit) != 0ull;
 		};
-		// Two steps stay in flight: beside the other chains' kernels a load takes longer than a step's arithmetic, and
-		// with one step in flight this kernel ran at the speed of the memory system (10 instead of 7 ms)
-		Dev3 cur = load_ahead(0), nxt = load_ahead(1);
-		int pd1 = 0, pd2 = 0;  // stage-1 outputs of the two samples before this step (same window)
-		while (j < count) {
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2  // instead: loop top -> recurrence | after candidates -> loop end
-			const long long pf_top = __builtin_readcyclecounter();
-#endif
-			// ---- (1) this step's inputs; the next two steps' are in flight
-			const int nv = cw.n - kStep * i < kStep ? cw.n - kStep * i : kStep;
-			const Dev3 nxt2 = load_ahead(2);
-			const int og = cw.og, n = cw.n;
-			uint32_t iqw = 0;  // the lane's decimated sample (rssi: only while the decoder is locked)
-			if (synced)
-				iqw = drow[og + kStep * i + ln];
-			const int dev = cur.d0;
-			const int devm1 = ln >= 1 ? cur.d1 : pd1;
-			const int devm2 = ln >= 2 ? cur.d2 : (ln == 1 ? pd1 : pd2);
-			if (i == 0) {
-				if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
-					rssi_d = 0;
-					rssi_acc = 0;
-					step0 = 0;
-					last_peak = 0;
-				}
-				if (ln == 0) {
-					WhbStart ws;
-					ws.sr = __brev(srr);
-					ws.lfsr = nh;
-					ws.sr_cnt = sc;
-					ws.byte_cnt = bc;
-					ws.synced = synced;
-					ws.pad_[0] = ws.pad_[1] = ws.pad_[2] = 0;
-					T.whbstart[(size_t)s * T.cap + j] = ws;
-				}
-			}
-			// dev > last_dev (whb.cpp:663); the window's first sample compares with the carried last_dev
-			const bool rise = dev > ((i == 0 && ln == 0) ? last_dev : devm1);
-			const bool unsynced0 = !synced;
-			int avgn = avg_of;
-			if (unsynced0) {
-				const double dn = 0.5 * (double)dev;  // whb.cpp:654
-				const bool first = i == 0;     // the window's first samples continue the carried filter inputs
-				const double dn1 = (first && ln == 0) ? f.dn1 : 0.5 * (double)devm1;
-				const double dn2 = (first && ln == 0) ? f.dn2 : ((first && ln == 1) ? f.dn1 : 0.5 * (double)devm2);
-				pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
-				__syncthreads();
-				// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association)
-#ifdef TFREC_AMD_PROFILE_WHB
-				const long long pf_a = __builtin_readcyclecounter();
-				pf_usteps++;
-#if TFREC_AMD_PROFILE_WHB == 2
-				pf_rec += pf_a - pf_top;
-#endif
-#endif
-				double y1 = f.yn, y2 = f.yn1;
-				// A full step: all feed-forward terms into registers first (the LDS reads are issued back to back, up to
-				// 15 in flight), then the bare chain, fully unrolled -- 47 cycles per sample instead of 76 for the rolled
-				// loop with a read per iteration (cycle counters, profiles/ubench/whb_cycles.py); the chain alone is 29.
-				if (nv == kStep) {
-					double2 v[kStep];
-#pragma unroll
-					for (int k = 0; k < kStep; k++)
-						v[k] = pb[k];
-#pragma unroll
-					for (int k = 0; k < kStep; k++) {
-						const double y = ((v[k].y + cavg.a1 * y1) + v[k].x) + cavg.a2 * y2;
-						yl[k] = y;
-						y2 = y1;
-						y1 = y;
-					}
-				} else
-#pragma unroll 4
-				for (int k = 0; k < nv; k++) {
-					const double2 v = pb[k];
-					const double y = ((v.y + cavg.a1 * y1) + v.x) + cavg.a2 * y2;
-					yl[k] = y;
-					y2 = y1;
-					y1 = y;
-				}
-				__syncthreads();
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB < 2
-				pf_rec += __builtin_readcyclecounter() - pf_a;
-#endif
-				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
-				avgn = (int)yl[ln];
-			}
-			// ---- (3) candidates: dev < avg_of && dev > last_dev
-			unsigned long long mask = __ballot(ln < nv && dev < avgn && rise);
+		// the run "0,1,1,.." of `len` bits through the sync search (cut to its first 160 bits: the registers reach a
+		// fixed point after 17 + 32 equal bits)
+		auto feed_run = [&](int len) -> bool {
+			bool hit = feed(~1u, len < 32 ? len : 32);
+			for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
+				hit = feed(~0u, rest < 32 ? rest : 32) || hit;
+			return hit;
+		};
+
+		for (int j = 0; j < count; j++) {
+			// ---- the window
+			const int og = T.open[(size_t)c * T.cap + j];
+			const int close = T.close[(size_t)c * T.cap + j];
+			const bool closed = close < M;
+			const int n = (closed ? close : M - 1) - og + 1;
+			const int nch = (n + kStep - 1) / kStep;
+			const int32_t *wp = dvrow + (size_t)win_slot0(og, j) * 32 + ln;  // the lane's stage-1 output of step 0
 			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
-			const long long base_step = step0 + (long long)kStep * i;
-			bool locked_here = false;
-			int rssi_from = synced ? 0 : kStep;  // first sample of the step that counts for the rssi
-			// ---- (4) accepted candidates
-#ifdef TFREC_AMD_PROFILE_WHB
-			const long long pf_c = __builtin_readcyclecounter();
-			pf_steps++;
-#endif
-			while (mask) {
-				const long long kmin = last_peak + tmin - base_step;  // first k with tdiff > 3*spb/4
-				if (kmin > kStep - 1)
-					break;
-				if (kmin > 0)
-					mask &= ~0ull << (int)kmin;
-				if (!mask)
-					break;
-				const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-				mask &= mask - 1;
-				const int tdiff = (int)(base_step + k - last_peak);
-				// whb.cpp:666-673: one 0, then (bit0 - 1) ones
-				const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
-				const int len = bit0 > 1 ? bit0 : 1;
-				if (ln == 0) {
-					if (len < kWhbRunEsc) {
-						ent[nent] = (uint16_t)len;
-					} else {
-						ent[nent] = (uint16_t)kWhbRunEsc;
-						ent[nent + 1] = (uint16_t)((uint32_t)len & 0xffff);
-						ent[nent + 2] = (uint16_t)((uint32_t)len >> 16);
-					}
-				}
-				nent += len < kWhbRunEsc ? 1 : 3;
-				// sync search over the run; the registers reach a fixed point after 17 + 32 equal bits, so a very
-				// long run of ones is cut to its first 160 bits
-				bool hit = feed(~1u, len < 32 ? len : 32);
-				for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
-					hit = feed(~0u, rest < 32 ? rest : 32) || hit;
-				if (!synced)
-					count_bits(len);
-				last_peak = base_step + k;
-				if (!synced && hit) {  // the decoder locked at sample k: rssi counts from k on (:677)
-					synced = 1;
-					rssi_from = k;
-					if (!iqw && rssi_from < nv)
-						iqw = drow[og + kStep * i + ln];
-					// the average stops after sample k (whb.cpp:653): state and avg_of as of k, and the rest of
-					// the step's candidates against the frozen avg_of
-					const double yk = yl[k], ykm1 = yl[k > 0 ? k - 1 : 0];
-					const int dk = __builtin_amdgcn_readlane(dev, k);
-					const int dkm1 = k > 0 ? __builtin_amdgcn_readlane(dev, k > 0 ? k - 1 : 0) : 0;
-					f.yn1 = k > 0 ? ykm1 : f.yn;
-					f.yn = yk;
-					f.dn2 = k > 0 ? 0.5 * (double)dkm1 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
-					f.dn1 = 0.5 * (double)dk;
-					avg_of = (int)yk;
-					mask = __ballot(ln < nv && ln > k && dev < avg_of && rise);
-					locked_here = true;
-				}
+			// two steps stay in flight (past the window's end: the row's next slots or the slack behind it, never used)
+			int cur = wp[0], nx1 = wp[kStep];
+			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
+				rssi_d = 0;
+				racc = 0;
+				step0 = 0;
+				since = 0;
 			}
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB < 2
-			pf_cand += __builtin_readcyclecounter() - pf_c;
-#endif
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB >= 2
-			const long long pf_post = __builtin_readcyclecounter();
-#endif
-			const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
-			const int dl2 = nv > 1 ? __builtin_amdgcn_readlane(dev, nv > 1 ? nv - 2 : 0) : pd1;
-			if (unsynced0 && !locked_here) {  // the whole step went through the average
-				const double ye = yl[nv - 1], yem1 = yl[nv > 1 ? nv - 2 : 0];
-				f.yn1 = nv > 1 ? yem1 : f.yn;
-				f.yn = ye;
-				f.dn2 = nv > 1 ? 0.5 * (double)dl2 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
-				f.dn1 = 0.5 * (double)dl1;
-				avg_of = (int)ye;
+			if (ln == 0) {
+				WhbStart ws;
+				ws.sr = __brev(srr);
+				ws.lfsr = nh;
+				ws.sr_cnt = sc;
+				ws.byte_cnt = bc;
+				ws.synced = synced;
+				ws.pad_[0] = ws.pad_[1] = ws.pad_[2] = 0;
+				T.whbstart[(size_t)s * T.cap + j] = ws;
 			}
-			last_dev = dl1;
-			pd2 = dl2;
-			pd1 = dl1;
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 3  // after the candidates -> state update | -> loop end
-			const long long pf_mid = __builtin_readcyclecounter();
-			pf_rec += pf_mid - pf_post;
-#endif
-			if (rssi_from < nv) {  // whb.cpp:677-678
-				const int I = (int)(int16_t)(iqw & 0xffff), Q = (int)iqw >> 16;
-				rssi_acc += wave_sum(ln >= rssi_from && ln < nv ? (unsigned long long)(uint32_t)(I * I + Q * Q) : 0ull);
-			}
-			if (i == cw.nch - 1) {  // last sample of the window in this submit
-				WinResult res;
-				res.nbits = nent;
-				res.closed = 0;
-				long long rssi_out = 0;
-				if (cw.closed) {  // timeout_cnt reached 0, whb.cpp:691-702
-					if (synced) {
-						(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
-						rssi_out = (long long)(rssi_d + (double)rssi_acc);
-						res.closed = 1;
-						srr = 0;
-						synced = 0;
-						sc = -1;
-						bc = 0;
-					}
-					rssi_d = 0;
-					rssi_acc = 0;
-					step0 = 0;
-					last_peak = 0;
-				} else {  // window continues in the next submit
-					rssi_d += (double)rssi_acc;
-					rssi_acc = 0;
-					step0 += n;
-				}
-				res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
-				res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
-				res.lbi_out = 0;
-				res.first_cand_g = -1;
-				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
-				res.resume = -1;
-				if (ln == 0)
-					T.result[(size_t)c * T.cap + j] = res;
-				nent = 0;
-			}
-			cur = nxt;
-			nxt = nxt2;
-			if (++i >= cw.nch) {
-				j++;
-				i = 0;
-				cw = nw;
-				nw = nnw;
-				nnw = read_win(j + 2);  // needed two windows from now: its latency is hidden
-			}
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 2
-			pf_cand += __builtin_readcyclecounter() - pf_post;
-#endif
-#if defined(TFREC_AMD_PROFILE_WHB) && TFREC_AMD_PROFILE_WHB == 3
-			pf_cand += __builtin_readcyclecounter() - pf_mid;
-#endif
-		}
-	}
-	if (ln == 0) {
-		const uint32_t lw = drow[M - 1];
-		st.prev_i = (int)(int16_t)(lw & 0xffff);
-		st.prev_q = (int)lw >> 16;
-		st.timeout_cnt = T.timeout_next[c];
-		st.last_dev = last_dev;
-		st.avg_of = avg_of;
-		st.step = (unsigned long long)step0;
-		st.last_peak = (unsigned long long)last_peak;
-		st.rssi_d = rssi_d;
-		st.iir_avg = f;
-	}
-#ifdef TFREC_AMD_PROFILE_WHB
-	if (ln == 0) {  // cycles: recurrence | candidate walk | whole demodulator; steps: all | with the recurrence
-		atomicAdd(&T.stats[5], (unsigned long long)pf_rec);
-		atomicAdd(&T.stats[6], (unsigned long long)pf_cand);
-		atomicAdd(&T.stats[7], (unsigned long long)(__builtin_readcyclecounter() - pf_t0));
-		atomicAdd(&T.stats[4], (unsigned long long)((pf_steps << 32) | pf_usteps));
-#ifdef TFREC_AMD_PROFILE_WHB_SPAN  // of the sixth submit: earliest / latest workgroup start, latest end (100 MHz ticks)
-		if (sample_base == 5LL * n_blocks * kBlockDec) {
-			atomicMax(&T.stats[1], ~(unsigned long long)pf_w0);
-			atomicMax(&T.stats[2], (unsigned long long)pf_w0);
-			atomicMax(&T.stats[3], (unsigned long long)wall_clock64());
-		}
-#endif
-	}
-#endif
-	// ---- decoder tail: the stream's windows, one per lane, then the stream's commit (lane 0)
-	__threadfence();  // lane 0's runs, results and start registers
-	__syncthreads();
-	for (int j = ln; j < count; j += 64)
-		whb_decode_window(s, j, n_streams, L, a, T, rdata_lds + 256 * ln);
-	__threadfence();
-	__syncthreads();
-	if (ln == 0)
-		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_lds);
-}
-
-// The same kernel with 128 samples per step (two per lane): the per-step work outside the recurrence -- prefetch
-// addressing, barriers, state update, window bookkeeping: 40 % of whb_demod_kernel's cycles -- is paid half as often.
-__global__ __launch_bounds__(64) void whb_demod128_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
-						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
-						       long long sample_base, ChainLaunch L, int a, WinTables T,
-						       tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 256 B, used by the decoder tail
-	__shared__ double2 pb[128];
-	__shared__ double yl[128];
-	constexpr int kStep = 128;  // samples per iteration: two per lane (ln and ln + 64)
-	const int ln = threadIdx.x;
-	const int s = blockIdx.x;  // one wave per stream
-	const ChainParams &p = L.params[a];
-	ChainState &st = L.states[a][s];
-	const int c = a * n_streams + s;
-	const int M = n_blocks * kBlockDec;
-	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const int32_t *dvrow = dev32 + (size_t)s * T.slots * 32;
-	const BiquadCoef cavg = p.iir_avg;
-	const double spb = p.spb;
-	const double thr = 3 * spb / 4;        // whb.cpp:664
-	const int tmin = (int)floor(thr) + 1;  // smallest integer tdiff with tdiff > thr
-	// (int)((tdiff + spb/2) / spb) is an exact shift when spb is a power of two (the reference's WHB: 64.0)
-	const int spb_i = (int)spb;
-	const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
-	const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
-	// ---- per-stream state, wave-uniform
-	Biquad f = st.iir_avg;
-	int avg_of = st.avg_of, last_dev = st.last_dev;
-	long long step0 = (long long)st.step, last_peak = (long long)st.last_peak;  // samples since the window opened
-	// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
-	// additions are exact in any order: the lanes add their samples' power in integers.
-	double rssi_d = st.rssi_d;             // rssi collected in earlier submits of a still-open window
-	unsigned long long rssi_acc = 0;       // ... and in this submit
-	int synced = st.synced;
-	// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
-	// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
-	uint32_t srr = __brev(st.sr);          // whb_decoder::sr, newest bit at the LSB
-	uint32_t nh = st.lfsr;                 // history of nrzs, newest at the LSB (whb.cpp:579)
-	const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
-	// sr_cnt / byte_cnt while the decoder has not locked since its last flush (they only matter before a stream's
-	// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
-	int sc = st.sr_cnt, bc = st.byte_cnt;
-	const int count = T.count[c];
-	const bool cont = T.cont[c] != 0;
-
-	auto wave_sum = [&](unsigned long long v) -> unsigned long long {
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1)
-			v += __shfl_xor(v, o, 64);
-		return v;
-	};
-	// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
-	auto feed = [&](uint32_t e, int len) -> bool {
-		const uint32_t emask = len >= 32 ? ~0u : (1u << len) - 1u;
-		const uint32_t nrun = __brev((e ^ kmask) & emask) >> (32 - len);           // nrzs of the run, newest at the LSB
-		const unsigned long long hn = ((unsigned long long)nh << len) | nrun;
-		const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;    // descrambled bits, whb.cpp:578
-		const unsigned long long sv = ((unsigned long long)srr << len) | orun;
-		const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
-		nh = (uint32_t)hn;
-		srr = (uint32_t)sv;
-		return __ballot(hit) != 0ull;
-	};
-	// sr_cnt / byte_cnt over `len` bits without a sync word (whb.cpp:590-596)
-	auto count_bits = [&](int len) {
-		if (sc >= 0) {
-			const int i0 = (8 - sc) & 7;  // first bit of the run that finds sr_cnt == 0
-			bc += i0 < len ? (len - 1 - i0) / 8 + 1 : 0;
-			sc = (sc + len) & 7;
-		}
-	};
-	struct Win {
-		int og, n, nch, slot0, closed;
-	};
-	auto read_win = [&](int jj) -> Win {
-		Win r;
-		const int jc = jj < count ? jj : (count > 0 ? count - 1 : 0);
-		r.og = T.open[(size_t)c * T.cap + jc];
-		const int close = T.close[(size_t)c * T.cap + jc];
-		r.closed = close < M;
-		r.n = (r.closed ? close : M - 1) - r.og + 1;
-		r.nch = (r.n + kStep - 1) / kStep;
-		r.slot0 = win_slot0(r.og, jc);
-		return r;
-	};
-	// the lane's two stage-1 outputs of a step (samples ln and ln + 64) and the two before each
-	struct Dev6 {
-		int a0, a1, a2, b0, b1, b2;
-	};
-	auto load_dev = [&](int slot0, int i) -> Dev6 {
-		const int idx = slot0 * 32 + kStep * i + ln;
-		Dev6 r;
-		r.a0 = dvrow[idx];
-		r.a1 = dvrow[idx > 0 ? idx - 1 : 0];
-		r.a2 = dvrow[idx > 1 ? idx - 2 : 0];
-		r.b0 = dvrow[idx + 64];
-		r.b1 = dvrow[idx + 63];
-		r.b2 = dvrow[idx + 62];
-		return r;
-	};
-	if (count > 0) {
-		Win cw = read_win(0), nw = read_win(1), nnw = read_win(2);
-		int j = 0, i = 0, nent = 0;
-		auto load_ahead = [&](int ahead) -> Dev6 {
-			int ii = i + ahead;
-			if (ii < cw.nch)
-				return load_dev(cw.slot0, ii);
-			ii -= cw.nch;
-			if (j + 1 < count) {
-				if (ii < nw.nch)
-					return load_dev(nw.slot0, ii);
-				ii -= nw.nch;
-				if (j + 2 < count && ii < nnw.nch)
-					return load_dev(nnw.slot0, ii);
-			}
-			return load_dev(cw.slot0, 0);
-		};
-		Dev6 cur = load_ahead(0), nxt = load_ahead(1);
-		int pd1 = 0, pd2 = 0;  // stage-1 outputs of the two samples before this step (same window)
-		while (j < count) {
-			// ---- (1) this step's inputs; the next two steps' are in flight
-			const int nv = cw.n - kStep * i < kStep ? cw.n - kStep * i : kStep;
-			const int nvA = nv < 64 ? nv : 64, nvB = nv - 64;  // valid samples of the two halves (nvB may be <= 0)
-			const Dev6 nxt2 = load_ahead(2);
-			const int og = cw.og, n = cw.n;
-			uint32_t iqA = 0, iqB = 0;  // the lane's decimated samples (rssi: only while the decoder is locked)
-			bool have_iq = false;
+			// run lengths of the accepted candidates: entry q of the window sits in lane q & 63 until 64 are complete
+			int nent = 0;
+			uint32_t entbuf = 0;
+			auto put_ent = [&](uint32_t v16) {
+				entbuf = ln == (nent & 63) ? v16 : entbuf;
+				nent++;
+				if ((nent & 63) == 0)
+					ent[nent - 64 + ln] = (uint16_t)entbuf;
+			};
+			// the lane's decimated sample of this step and the next (rssi: only while the decoder is locked)
+			auto iq_load = [&](int i) -> uint32_t {
+				const int g = og + kStep * i + ln;
+				return drow[g < M ? g : M - 1];
+			};
+			uint32_t iq0 = 0, iq1 = 0;
 			if (synced) {
-				iqA = drow[og + kStep * i + ln];
-				iqB = drow[og + kStep * i + 64 + ln < M ? og + kStep * i + 64 + ln : M - 1];
-				have_iq = true;
+				iq0 = iq_load(0);
+				iq1 = iq_load(1);
 			}
-			const int devA = cur.a0, devB = cur.b0;
-			const int devm1A = ln >= 1 ? cur.a1 : pd1;
-			const int devm2A = ln >= 2 ? cur.a2 : (ln == 1 ? pd1 : pd2);
-			const int devm1B = cur.b1, devm2B = cur.b2;
-			if (i == 0) {
-				if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
-					rssi_d = 0;
-					rssi_acc = 0;
-					step0 = 0;
-					last_peak = 0;
-				}
-				if (ln == 0) {
-					WhbStart ws;
-					ws.sr = __brev(srr);
-					ws.lfsr = nh;
-					ws.sr_cnt = sc;
-					ws.byte_cnt = bc;
-					ws.synced = synced;
-					ws.pad_[0] = ws.pad_[1] = ws.pad_[2] = 0;
-					T.whbstart[(size_t)s * T.cap + j] = ws;
-				}
-			}
-			// dev > last_dev (whb.cpp:663); the window's first sample compares with the carried last_dev
-			const bool riseA = devA > ((i == 0 && ln == 0) ? last_dev : devm1A);
-			const bool riseB = devB > devm1B;
-			const bool unsynced0 = !synced;
-			int avgnA = avg_of, avgnB = avg_of;
-			if (unsynced0) {
-				const bool first = i == 0;  // the window's first samples continue the carried filter inputs
-				{
-					const double dn = 0.5 * (double)devA;  // whb.cpp:654
-					const double dn1 = (first && ln == 0) ? f.dn1 : 0.5 * (double)devm1A;
-					const double dn2 = (first && ln == 0) ? f.dn2 : ((first && ln == 1) ? f.dn1 : 0.5 * (double)devm2A);
-					pb[ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
-				}
-				{
-					const double dn = 0.5 * (double)devB, dn1 = 0.5 * (double)devm1B, dn2 = 0.5 * (double)devm2B;
-					pb[64 + ln] = make_double2(cavg.b0 * dn + cavg.b1 * dn1, cavg.b2 * dn2);
-				}
-				__syncthreads();
-				// ---- (2) the serial feedback recurrence (iir2::step, see iir_step() for the association): 64 samples at
-				// a time with all feed-forward terms in registers first (see whb_demod_kernel), then what is left
-				double y1 = f.yn, y2 = f.yn1;
-				int k0 = 0;
-#pragma unroll 1
-				for (; k0 + 64 <= nv; k0 += 64) {
-					double2 v[64];
-#pragma unroll
-					for (int k = 0; k < 64; k++)
-						v[k] = pb[k0 + k];
-#pragma unroll
-					for (int k = 0; k < 64; k++) {
-						const double y = ((v[k].y + cavg.a1 * y1) + v[k].x) + cavg.a2 * y2;
-						yl[k0 + k] = y;
-						y2 = y1;
-						y1 = y;
+			for (int i = 0; i < nch; i++) {
+				// ---- (1) this step's inputs; the next two steps' are in flight
+				const int nv = n - kStep * i < kStep ? n - kStep * i : kStep;
+				const int nx2 = wp[kStep * (i + 2)];
+				const int dev = cur;
+				const int sh1 = wave_shr1(dev);
+				const int devm1 = ln == 0 ? last_dev : sh1;  // dev > last_dev (whb.cpp:663): the sample before the step
+				const bool rise = dev > devm1;
+				const bool was_synced = synced != 0;
+				unsigned long long mask;
+				const double y1_in = y1;
+				double ym = 0.0;  // the average after the lane's sample (while the decoder is unsynced)
+#ifdef TFREC_AMD_PROFILE_WHB
+				pf_steps++;
+				pf_mark = __builtin_readcyclecounter();
+#endif
+				if (!was_synced) {
+					// ---- (2) feed-forward half of iir2::step for the lane's sample (see iir_step_t)
+					const int devm1f = ln == 0 ? fd1 : sh1;  // the filter's own input history (it pauses while synced)
+					const int sh2 = wave_shr1(devm1f);
+					const int devm2f = ln == 0 ? fd2 : sh2;
+					const double t0 = bh * (double)dev, t1 = bh * (double)devm1f, t2 = bh * (double)devm2f;
+					const double ffp = __builtin_fma(2.0, t1, t0);  // P; B2 = t2
+#ifdef TFREC_AMD_PROFILE_WHB
+					const long long pf_a = __builtin_readcyclecounter();
+					pf_usteps++;
+					pf_top += pf_a - pf_mark;
+#endif
+					// ---- (3) the serial feedback recurrence, 64 samples (a window's last, partial step runs it over whatever
+					// follows the window: finite numbers, never looked at): whb_chain_asm.h.  The feed-forward pairs as four
+					// row-replicated sets: lane 16r + i holds sample 16j + i of set j.
+					// (two v_permlane16/32_swap levels per dword: no LDS round trip in the step -- the CU's LDS pipe belongs to
+					// the front end's workgroups, and a lone wave waiting behind them was the slowest stream of the batch)
+					double inp[4], inb[4];
+					rows_replicate(ffp, inp);
+					rows_replicate(t2, inb);
+					double z0, z1, z2, z3, tt, tq, ya = 0.0, yb = 0.0, yc = y2, yd = y1;
+					asm volatile(TFREC_WHB_CHAIN_ASM
+						     : [Y0] "+v"(ya), [Y1] "+v"(yb), [Y2] "+v"(yc), [Y3] "+v"(yd), [Z0] "=&v"(z0), [Z1] "=&v"(z1),
+						       [Z2] "=&v"(z2), [Z3] "=&v"(z3), [T] "=&v"(tt), [Q] "=&v"(tq)
+						     : [a1] "s"(a1), [a2] "s"(a2), [ONE] "v"(1.0), [P0] "v"(inp[0]), [B0] "v"(inb[0]), [P1] "v"(inp[1]),
+						       [B1] "v"(inb[1]), [P2] "v"(inp[2]), [B2] "v"(inb[2]), [P3] "v"(inp[3]), [B3] "v"(inb[3]));
+					const int zq = ln & 3;
+					ym = zq == 0 ? z0 : (zq == 1 ? z1 : (zq == 2 ? z2 : z3));  // y(ln)
+					if (nv == kStep) {
+						y1 = yd;
+						y2 = yc;
+					} else {  // the filter stops with the window's last sample
+						y1 = readlane_f64(ym, nv - 1);
+						y2 = nv > 1 ? readlane_f64(ym, nv > 1 ? nv - 2 : 0) : y1_in;
 					}
+#ifdef TFREC_AMD_PROFILE_WHB
+					pf_mark = __builtin_readcyclecounter();
+					pf_rec += pf_mark - pf_a;
+#endif
+					// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
+					mask = __ballot(ln < nv && dev < (int)ym && rise);
+				} else {
+					mask = __ballot(ln < nv && dev < avg_of && rise);
 				}
-#pragma unroll 4
-				for (int k = k0; k < nv; k++) {
-					const double2 v = pb[k];
-					const double y = ((v.y + cavg.a1 * y1) + v.x) + cavg.a2 * y2;
-					yl[k] = y;
-					y2 = y1;
-					y1 = y;
-				}
-				__syncthreads();
-				// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
-				avgnA = (int)yl[ln];
-				avgnB = (int)yl[64 + ln];
-			}
-			// ---- (3) + (4): candidates dev < avg_of && dev > last_dev, half by half
-			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
-			const long long base_step = step0 + (long long)kStep * i;
-			bool locked_here = false;
-			int rssi_from = synced ? 0 : kStep;  // first sample of the step that counts for the rssi
-#pragma unroll
-			for (int half = 0; half < 2; half++) {
-				const int dev = half ? devB : devA;
-				const bool rise = half ? riseB : riseA;
-				const int nvh = half ? nvB : nvA;
-				const int kofs = 64 * half;
-				// (a lock in the first half froze avg_of: the second half is tested against it)
-				const int avgn = synced ? avg_of : (half ? avgnB : avgnA);
-				unsigned long long mask = __ballot(ln < nvh && dev < avgn && rise);
+				// ---- (4) accepted candidates
+				int locked_at = -1;
 				while (mask) {
-					const long long kmin = last_peak + tmin - base_step - kofs;  // first k with tdiff > 3*spb/4
-					if (kmin > 63)
+					const long long kmin = (long long)tmin - since;  // first k with tdiff > 3*spb/4
+					if (kmin > kStep - 1)
 						break;
 					if (kmin > 0)
 						mask &= ~0ull << (int)kmin;
 					if (!mask)
 						break;
-					const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+					const int k = __builtin_ctzll(mask);
 					mask &= mask - 1;
-					const int kg = kofs + k;  // sample index in the step
-					const int tdiff = (int)(base_step + kg - last_peak);
+					const int tdiff = (int)(since + k);
 					// whb.cpp:666-673: one 0, then (bit0 - 1) ones
 					const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
 					const int len = bit0 > 1 ? bit0 : 1;
-					if (ln == 0) {
-						if (len < kWhbRunEsc) {
-							ent[nent] = (uint16_t)len;
-						} else {
-							ent[nent] = (uint16_t)kWhbRunEsc;
-							ent[nent + 1] = (uint16_t)((uint32_t)len & 0xffff);
-							ent[nent + 2] = (uint16_t)((uint32_t)len >> 16);
+					if (len < kWhbRunEsc) {
+						put_ent((uint32_t)len);
+					} else {
+						put_ent((uint32_t)kWhbRunEsc);
+						put_ent((uint32_t)len & 0xffffu);
+						put_ent((uint32_t)len >> 16);
+					}
+					const bool hit = feed_run(len);
+					since = -(long long)k;  // last_peak = this sample
+					if (!synced) {
+						if (sc >= 0) {  // sr_cnt / byte_cnt over `len` bits without a sync word (whb.cpp:590-596)
+							const int i0 = (8 - sc) & 7;  // first bit of the run that finds sr_cnt == 0
+							bc += i0 < len ? (len - 1 - i0) / 8 + 1 : 0;
+							sc = (sc + len) & 7;
+						}
+						if (hit) {  // the decoder locked at sample k: the average stops after it (whb.cpp:653)
+							synced = 1;
+							locked_at = k;
+							const double yk = readlane_f64(ym, k), ykm1 = readlane_f64(ym, k > 0 ? k - 1 : 0);
+							const int dk = __builtin_amdgcn_readlane(dev, k);
+							const int dkm1 = __builtin_amdgcn_readlane(dev, k > 0 ? k - 1 : 0);
+							y2 = k > 0 ? ykm1 : y1_in;
+							y1 = yk;
+							fd2 = k > 0 ? dkm1 : fd1;
+							fd1 = dk;
+							avg_of = (int)yk;
+							// the rest of the step's candidates against the frozen avg_of
+							mask = __ballot(ln < nv && ln > k && dev < avg_of && rise);
 						}
 					}
-					nent += len < kWhbRunEsc ? 1 : 3;
-					bool hit = feed(~1u, len < 32 ? len : 32);
-					for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
-						hit = feed(~0u, rest < 32 ? rest : 32) || hit;
-					if (!synced)
-						count_bits(len);
-					last_peak = base_step + kg;
-					if (!synced && hit) {  // the decoder locked at sample kg: rssi counts from there on (:677)
-						synced = 1;
-						rssi_from = kg;
-						if (!have_iq) {
-							iqA = drow[og + kStep * i + ln];
-							iqB = drow[og + kStep * i + 64 + ln < M ? og + kStep * i + 64 + ln : M - 1];
-							have_iq = true;
-						}
-						// the average stops after sample kg (whb.cpp:653): state and avg_of as of kg, and the rest of
-						// the step's candidates against the frozen avg_of
-						const double yk = yl[kg], ykm1 = yl[kg > 0 ? kg - 1 : 0];
-						const int dk = __builtin_amdgcn_readlane(dev, k);
-						// the sample before kg: same half, or the first half's last lane
-						const int dkm1 = k > 0 ? __builtin_amdgcn_readlane(dev, k > 0 ? k - 1 : 0)
-								       : (half ? __builtin_amdgcn_readlane(devA, 63) : 0);
-						f.yn1 = kg > 0 ? ykm1 : f.yn;
-						f.yn = yk;
-						f.dn2 = kg > 0 ? 0.5 * (double)dkm1 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
-						f.dn1 = 0.5 * (double)dk;
-						avg_of = (int)yk;
-						mask = __ballot(ln < nvh && ln > k && dev < avg_of && rise);
-						locked_here = true;
-					}
 				}
-			}
-			// the step's last two samples
-			const int dl1 = nv > 64 ? __builtin_amdgcn_readlane(devB, nv > 64 ? nv - 65 : 0) : __builtin_amdgcn_readlane(devA, nv - 1);
-			const int dl2 = nv > 65 ? __builtin_amdgcn_readlane(devB, nv > 65 ? nv - 66 : 0)
-					       : (nv > 1 ? __builtin_amdgcn_readlane(devA, nv > 1 ? (nv == 65 ? 63 : nv - 2) : 0) : pd1);
-			if (unsynced0 && !locked_here) {  // the whole step went through the average
-				const double ye = yl[nv - 1], yem1 = yl[nv > 1 ? nv - 2 : 0];
-				f.yn1 = nv > 1 ? yem1 : f.yn;
-				f.yn = ye;
-				f.dn2 = nv > 1 ? 0.5 * (double)dl2 : ((i == 0) ? f.dn1 : 0.5 * (double)pd1);
-				f.dn1 = 0.5 * (double)dl1;
-				avg_of = (int)ye;
-			}
-			last_dev = dl1;
-			pd2 = dl2;
-			pd1 = dl1;
-			if (rssi_from < nv) {  // whb.cpp:677-678
-				const int IA = (int)(int16_t)(iqA & 0xffff), QA = (int)iqA >> 16;
-				const int IB = (int)(int16_t)(iqB & 0xffff), QB = (int)iqB >> 16;
-				const unsigned long long pa = ln >= rssi_from && ln < nvA ? (unsigned long long)(uint32_t)(IA * IA + QA * QA) : 0ull;
-				const unsigned long long pq = 64 + ln >= rssi_from && ln < nvB ? (unsigned long long)(uint32_t)(IB * IB + QB * QB) : 0ull;
-				rssi_acc += wave_sum(pa + pq);
-			}
-			if (i == cw.nch - 1) {  // last sample of the window in this submit
-				WinResult res;
-				res.nbits = nent;
-				res.closed = 0;
-				long long rssi_out = 0;
-				if (cw.closed) {  // timeout_cnt reached 0, whb.cpp:691-702
-					if (synced) {
-						(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
-						rssi_out = (long long)(rssi_d + (double)rssi_acc);
-						res.closed = 1;
-						srr = 0;
-						synced = 0;
-						sc = -1;
-						bc = 0;
-					}
-					rssi_d = 0;
-					rssi_acc = 0;
-					step0 = 0;
-					last_peak = 0;
-				} else {  // window continues in the next submit
-					rssi_d += (double)rssi_acc;
-					rssi_acc = 0;
-					step0 += n;
+#ifdef TFREC_AMD_PROFILE_WHB
+				{
+					const long long t = __builtin_readcyclecounter();
+					pf_walk += t - pf_mark;
+					pf_mark = t;
 				}
-				res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
-				res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
-				res.lbi_out = 0;
-				res.first_cand_g = -1;
-				res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
-				res.resume = -1;
-				if (ln == 0)
-					T.result[(size_t)c * T.cap + j] = res;
-				nent = 0;
+#endif
+				// ---- (5) the step's state
+				const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
+				if (!was_synced && locked_at < 0) {  // the whole step went through the average
+					fd2 = nv > 1 ? __builtin_amdgcn_readlane(dev, nv > 1 ? nv - 2 : 0) : fd1;
+					fd1 = dl1;
+					avg_of = (int)y1;
+				}
+				last_dev = dl1;
+				since += nv;
+				if (synced) {  // whb.cpp:677-678: from the sample at which the decoder locked on
+					uint32_t w = iq0;
+					if (locked_at >= 0) {
+						w = iq_load(i);
+						iq1 = iq_load(i + 1);
+					}
+					const int I = (int)(int16_t)(w & 0xffff), Q = (int)w >> 16;
+					if (ln < nv && ln >= locked_at)
+						racc += (unsigned long long)(uint32_t)(I * I + Q * Q);
+					iq0 = iq1;
+					iq1 = iq_load(i + 2);
+				}
+				cur = nx1;
+				nx1 = nx2;
+#ifdef TFREC_AMD_PROFILE_WHB
+				pf_tail += __builtin_readcyclecounter() - pf_mark;
+#endif
 			}
-			cur = nxt;
-			nxt = nxt2;
-			if (++i >= cw.nch) {
-				j++;
-				i = 0;
-				cw = nw;
-				nw = nnw;
-				nnw = read_win(j + 2);  // needed two windows from now: its latency is hidden
+			// ---- the window's last sample in this submit
+			if (nent & 63)
+				if (ln < (nent & 63))
+					ent[(nent & ~63) + ln] = (uint16_t)entbuf;
+			WinResult res;
+			res.nbits = nent;
+			res.closed = 0;
+			long long rssi_out = 0;
+			if (closed) {  // timeout_cnt reached 0, whb.cpp:691-702
+				if (synced) {
+					unsigned long long tot = racc;
+#pragma unroll
+					for (int o = 32; o >= 1; o >>= 1)
+						tot += __shfl_xor(tot, o, 64);
+					(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
+					rssi_out = (long long)(rssi_d + (double)tot);
+					res.closed = 1;
+					srr = 0;
+					synced = 0;
+					sc = -1;
+					bc = 0;
+				}
+				rssi_d = 0;
+				racc = 0;
+				step0 = 0;
+				since = 0;
+			} else {  // the window continues in the next submit
+				unsigned long long tot = racc;
+#pragma unroll
+				for (int o = 32; o >= 1; o >>= 1)
+					tot += __shfl_xor(tot, o, 64);
+				rssi_d += (double)tot;
+				racc = 0;
+				step0 += n;
 			}
+			res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
+			res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
+			res.lbi_out = 0;
+			res.first_cand_g = -1;
+			res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
+			res.resume = -1;
+			if (ln == 0)
+				T.result[(size_t)c * T.cap + j] = res;
 		}
-	}
-	if (ln == 0) {
-		const uint32_t lw = drow[M - 1];
+		if (ln == 0) {
+			const uint32_t lw = drow[M - 1];
+			st.prev_i = (int)(int16_t)(lw & 0xffff);
+			st.prev_q = (int)lw >> 16;
+			st.timeout_cnt = T.timeout_next[c];
+			st.last_dev = last_dev;
+			st.avg_of = avg_of;
+			st.step = (unsigned long long)step0;
+			st.last_peak = (unsigned long long)(step0 - since);
+			st.rssi_d = rssi_d;
+			st.iir_avg.yn = y1;
+			st.iir_avg.yn1 = y2;
+			st.iir_avg.dn1 = 0.5 * (double)fd1;
+			st.iir_avg.dn2 = 0.5 * (double)fd2;
+		}
+	} else if (ln == 0) {  // no window in this submit: only the carried sample and timeout move on
+		ChainState &st = L.states[a][s];
+		const uint32_t lw = dec[(size_t)s * dec_stride + M - 1];
 		st.prev_i = (int)(int16_t)(lw & 0xffff);
 		st.prev_q = (int)lw >> 16;
 		st.timeout_cnt = T.timeout_next[c];
-		st.last_dev = last_dev;
-		st.avg_of = avg_of;
-		st.step = (unsigned long long)step0;
-		st.last_peak = (unsigned long long)last_peak;
-		st.rssi_d = rssi_d;
-		st.iir_avg = f;
 	}
+#ifdef TFREC_AMD_PROFILE_WHB
+	if (ln == 0) {  // cycles: recurrence | whole demodulator; steps: all | with the recurrence
+#ifndef TFREC_AMD_PROFILE_WHB_SPAN
+		atomicAdd(&T.stats[5], (unsigned long long)pf_rec);
+#endif
+#ifdef TFREC_AMD_PROFILE_WHB_SPAN  // of the sixth submit: earliest / latest workgroup start, latest end (100 MHz ticks), sum of starts
+		if (sample_base == 5LL * n_blocks * kBlockDec) {
+			atomicMax(&T.stats[1], ~(unsigned long long)pf_w0);
+			atomicMax(&T.stats[2], (unsigned long long)pf_w0);
+			atomicMax(&T.stats[3], (unsigned long long)wall_clock64());
+			atomicAdd(&T.stats[0], (unsigned long long)pf_w0 & 0xffffffffffull);
+			// the slowest stream: its cycles (high 40 bits) and steps (low 24)
+			atomicMax(&T.stats[5], ((unsigned long long)(__builtin_readcyclecounter() - pf_t0) << 24) | (unsigned long long)pf_steps);
+			{  // histogram of the streams' cycles per step (x100), 5 buckets of 12 bits: < 25, < 30, < 35, < 45, more
+				const long long cps = (__builtin_readcyclecounter() - pf_t0) / (pf_steps > 0 ? pf_steps : 1) / 100;
+				const int b = cps < 25 ? 0 : (cps < 30 ? 1 : (cps < 35 ? 2 : (cps < 45 ? 3 : 4)));
+				atomicAdd(&T.stats[6], 1ull << (12 * b));
+			}
+		}
+#else
+		atomicAdd(&T.stats[1], (unsigned long long)pf_top);
+		atomicAdd(&T.stats[2], (unsigned long long)pf_walk);
+		atomicAdd(&T.stats[3], (unsigned long long)pf_tail);
+#endif
+		atomicAdd(&T.stats[7], (unsigned long long)(__builtin_readcyclecounter() - pf_t0));
+#ifndef TFREC_AMD_PROFILE_WHB_SPAN
+		atomicAdd(&T.stats[6], (unsigned long long)(wall_clock64() - pf_w0));
+#endif
+		atomicAdd(&T.stats[4], (unsigned long long)((pf_steps << 32) | pf_usteps));
+	}
+#endif
 	// ---- decoder tail: the stream's windows, one per lane, then the stream's commit (lane 0)
-	__threadfence();  // lane 0's runs, results and start registers
+	__threadfence();  // the runs, results and start registers
 	__syncthreads();
 	for (int j = ln; j < count; j += 64)
-		whb_decode_window(s, j, n_streams, L, a, T, rdata_lds + 256 * ln);
+		whb_decode_window(s, j, n_streams, L, a, T, rdata_lds + 64 * ln);
 	__threadfence();
 	__syncthreads();
 	if (ln == 0)
@@ -2885,23 +2543,13 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		mark(22, P.aux);
 		for (int a = 0; a < L.n_active; a++)
 			if (L.params[a].kind == 2) {
-				// 16 KB of dynamic LDS (the decoder tail of the kernel uses it): at most 9 of this kernel's one-wave workgroups
-				// fit on a CU.  It is launched while the other chains' kernels occupy the chip; without a cap the dispatcher
-				// piled its waves onto the few CUs that happened to have room, where they shared SIMDs with each other for
-				// their whole life (10.4 -> 8.5 ms when the cap was introduced, then 22 KB = 7 per CU; with the deep layout
-				// 16 KB measures 3 % better than 22 KB, and 30 KB 8 % worse).  TFREC_AMD_WHB_LDS raises it.
-				static const int whb_lds = std::max(64 * 256, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
-				// 128 samples per step: the kernel itself is 7-10 % faster, and a batch with only WHB registered with it
-				// (6.4 instead of 7.1 ms); beside the TFA chains the batch came out 2 % slower (9.65 vs 9.45 ms), so
-				// it is the default only when WHB runs alone.  TFREC_AMD_WHB128 = 0 / 1 forces one or the other.
-				static const int step128_env = env_int("TFREC_AMD_WHB128", -1, -1, 1);
-				const bool step128 = step128_env >= 0 ? step128_env != 0 : !(has_tfa1 || has_tfa2);
-				if (step128)
-					hipLaunchKernelGGL(whb_demod128_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32,
-							   n_streams, n_blocks, sample_base, L, a, T, events, eb, flags);
-				else
-					hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
-							   n_blocks, sample_base, L, a, T, events, eb, flags);
+				// 4 KB of dynamic LDS for the decoder tail (64 lanes x rdata[0 .. 64)).  The kernel is launched while the other
+				// chains' kernels occupy the chip, and its one-wave workgroups go wherever LDS is free: beside six resident
+				// front-end workgroups (25 KB each of the CU's 160 KB) the 17 KB it used to ask for did not fit at all, so it
+				// trickled onto the chip at the front end's pace.  TFREC_AMD_WHB_LDS raises it (caps the workgroups per CU).
+				static const int whb_lds = std::max(64 * 64, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
+				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
+						   n_blocks, sample_base, L, a, T, events, eb, flags);
 				mark(13, P.aux);
 				mark(14, P.aux);
 				mark(15, P.aux);

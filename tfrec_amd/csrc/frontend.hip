@@ -19,12 +19,16 @@
 // once: one VALU instruction per tap and complex sample, where the integer form (v_mul_hi_i32_i24 + add) took 3.5.
 // Stage 1 with u8 input uses ((u8-128)*h) >> 10 (identical value, the <<6 cancels).
 //
-// MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  The tile's
-// raw bytes (8 KiB + 112 B halo, the halo of the first tile comes from the previous submit's tail) are
-// staged into LDS with coalesced 16-byte loads, stage-1 outputs live only in LDS ((I, Q) float pairs, read
-// back with ds_read_b128), stage-2 results leave as one 16-byte store per thread, and the trigger bits of
+// MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  A lane reads the
+// 28 raw bytes of a stage-1 group (4 outputs of both rails) straight from global memory with two unaligned vector
+// loads -- neighbouring lanes overlap, so the tile streams its 8 KiB + 112 B halo once (the halo of a submit's first
+// tile comes from the previous submit's tail); stage-1 outputs live only in LDS ((I, Q) float pairs, 16.6 KB per
+// workgroup: the raw bytes used to be staged there too, 25 KB, which capped the kernel at 6 workgroups per CU),
+// read back with ds_read_b128; stage-2 results leave as one 16-byte store per thread, and the trigger bits of
 // 64 consecutive samples are packed into one 64-bit word per wave-quarter with wave ballots.  No MFMA: the
 // path is a streaming stencil with a per-tap rounding, bound by HBM bytes and VALU issue.
+#include <stdlib.h>
+
 #include "dsp_dev.h"
 
 namespace tfrec {
@@ -33,6 +37,8 @@ __device__ __constant__ double kAtanPolyFront[11] = TFREC_ATAN_POLY;  // see dsp
 
 // first-stage taps (dsp_stuff.cpp:119-130)
 __device__ __constant__ const int kS1[8] = { 2443, 6339, 11036, 14254, 14254, 11036, 6339, 2443 };
+
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load, dword aligned
 
 __device__ __forceinline__ unsigned long long spread4(unsigned long long x)
 {
@@ -55,8 +61,6 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 {
 	constexpr int kB = IN16 ? 2 : 1;             // bytes per rail sample
 	constexpr int kTail = kTailBytes * kB;      // history bytes (56 complex samples)
-	constexpr int kChunks = (kTail + 8 * kB * kTileDec + 16 * kB + 15) / 16;
-	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
 	typedef float f32x2 __attribute__((ext_vector_type(2)));
 	typedef float f32x4 __attribute__((ext_vector_type(4)));
 	__shared__ __attribute__((aligned(16))) f32x2 y1[kY1Count];  // stage-1 outputs as (I, Q) pairs of floats
@@ -70,33 +74,51 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	// MODE.FP_ROUND (fp32) = 2, round toward -inf: see stage 1.  Every fp32 operation of this kernel is either one of
 	// those FMAs or exact.
 	__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);
+#ifdef TFREC_AMD_FE_PRIO
+	__builtin_amdgcn_s_setprio(TFREC_AMD_FE_PRIO);
+#endif
 	const uint8_t *src = iq + (size_t)s * stride;
-
-	// ---- stage raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) into LDS, 16 B per lane, coalesced
+	// The tile reads raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) straight from global memory: a lane's 28 bytes per
+	// stage-1 group overlap its neighbours' (16-byte stride), so the second load of a group hits what the first one of
+	// the next lane brought in; the 112 bytes before the submit come from the previous one's tail, what lies behind its
+	// end is silence (only the last tile's last groups look there, and their outputs are never used).
 	const long base = 8L * kB * m0 - kTail;
 	const uint32_t silence = IN16 ? 0u : 0x80808080u;
-	for (int c = tid; c < kChunks; c += kFrontThreads) {
-		const long bo = base + 16L * c;
-		uint4 v;
-		if (bo >= 0 && bo + 16 <= nbytes)
-			v = *reinterpret_cast<const uint4 *>(src + bo);
-		else if (bo < 0)
-			v = *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTail + (kTail + bo));
-		else
-			v = make_uint4(silence, silence, silence, silence);
-		*reinterpret_cast<uint4 *>(raw + 16 * c) = v;
-	}
+	auto raw_dword = [&](long bo) -> uint32_t {  // bo: byte offset into the stream, 4-byte aligned; edges only
+		if (bo >= 0 && bo + 4 <= nbytes)
+			return *reinterpret_cast<const uint32_t *>(src + bo);
+		if (bo < 0)
+			return *reinterpret_cast<const uint32_t *>(tail_in + (size_t)s * kTail + (kTail + bo));
+		return silence;
+	};
 	// history for the next submit: the last 56 raw complex samples of this one
 	if (tile == (int)gridDim.x - 1 && tid < kTail / 16)
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTail + 16 * tid);
-	__syncthreads();
 
 	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes 4 consecutive outputs of both rails.
-	// Outputs k..k+3 need x[2k-6 .. 2k+7]: 28 raw bytes at LDS offset 12 + 16*grp (k = 2*m0 - 22 + 4*grp).
+	// Outputs k..k+3 need x[2k-6 .. 2k+7]: 28 raw bytes at offset base + 12 + 16*grp (k = 2*m0 - 22 + 4*grp).
 	constexpr int kGroups = (2 * kTileDec + 24 + 3) / 4;
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
-		const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + kB * (12 + 16 * grp));
+		uint32_t rp[7 * kB];
+		{
+			const long bo = base + kB * (12 + 16 * grp);
+			if (bo >= 0 && bo + 28 * kB <= nbytes) {
+				const u32x4_u *g = reinterpret_cast<const u32x4_u *>(src + bo);
+#pragma unroll
+				for (int q = 0; q < (7 * kB) / 4; q++) {
+					const u32x4_u v = g[q];
+					rp[4 * q] = v.x; rp[4 * q + 1] = v.y; rp[4 * q + 2] = v.z; rp[4 * q + 3] = v.w;
+				}
+#pragma unroll
+				for (int q = 4 * ((7 * kB) / 4); q < 7 * kB; q++)
+					rp[q] = reinterpret_cast<const uint32_t *>(src + bo)[q];
+			} else {
+#pragma unroll
+				for (int q = 0; q < 7 * kB; q++)
+					rp[q] = raw_dword(bo + 4 * q);
+			}
+		}
 		f32x2 oy[4];
 		if (IN16) {
 			// int16 input: the same FMA form (below) with x * (h / 65536); x * h has up to 30 bits, which the FMA does not
@@ -341,11 +363,13 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 {
 	const int m_total = n_blocks * kBlockDec;
 	dim3 grid(m_total / kTileDec, n_streams);
+	// experiment knob: extra dynamic LDS per workgroup (caps the front end's workgroups per CU)
+	static const int pad = getenv("TFREC_AMD_FE_LDS_PAD") ? atoi(getenv("TFREC_AMD_FE_LDS_PAD")) : 0;
 	if (in16)
-		hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out,
+		hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kFrontThreads), pad, st, iq, stride, m_total, tail_in, tail_out,
 				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
 	else
-		hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(kFrontThreads), 0, st, iq, stride, m_total, tail_in, tail_out,
+		hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(kFrontThreads), pad, st, iq, stride, m_total, tail_in, tail_out,
 				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
 	return hipGetLastError();
 }
