@@ -17,6 +17,9 @@
 //
 // Modes:
 //   ref_driver run  <types_hex> <thresh> <wide 0|1> <iqfile> [events_out] [dec_out] [bits 0|1]
+//   ref_driver runh <types_hex> <thresh> <wide 0|1> <iqfile> <mode 0|1>   (handler "echo REC": the reference's own
+//                   execute_handler() command lines, decoder.cpp:67-96, come out as "REC <args>" lines; mode = its -m;
+//                   flush_storage() of every decoder at the end like main.cpp:231-234)
 //   ref_driver hex  <types_hex> <hexfile>
 //   ref_driver time <types_hex> <thresh> <wide 0|1> <iqfile> <repeat>
 //   ref_driver fmdev            (stdin int32[4] records -> stdout int32[2]: fm_dev, fm_dev_nrzs)
@@ -228,6 +231,30 @@ int main(int argc, char **argv)
 			run_stream(iq, len, fsk, wide, dec_fd);
 		if (ev_fd) fclose(ev_fd);
 		if (dec_fd) fclose(dec_fd);
+		fflush(stdout);
+		return 0;
+	}
+	if (!strcmp(argv[1], "runh") && argc >= 7) {
+		int types = strtol(argv[2], NULL, 16);
+		int thresh = atoi(argv[3]);
+		int wide = atoi(argv[4]);
+		int mode = atoi(argv[6]);
+		size_t len;
+		unsigned char *iq = read_file(argv[5], &len);
+		vector<demodulator *> demods;
+		register_demods(demods, types, -1);  // quiet: only the handler's lines
+		static char handler[] = "echo REC";
+		if (argc > 7)
+			ev_fd = fopen(argv[7], "w");
+		for (size_t n = 0; n < demods.size(); n++)
+			demods[n]->dec->set_params(handler, mode, -1);
+		fsk_demod fsk(&demods, thresh, -1);
+		puts("---");
+		fflush(stdout);
+		run_stream(iq, len, fsk, wide, NULL);
+		fflush(stdout);
+		for (size_t n = 0; n < demods.size(); n++)
+			demods[n]->dec->flush_storage();
 		fflush(stdout);
 		return 0;
 	}

@@ -106,3 +106,72 @@ def test_batched_sink_on_dump_replay(cli, golden_dir, tmp_path):
     assert len(recs) >= 20 and {r[0] for r in recs} == {"0", "1", "2"}
     # every record corresponds to a printed telegram (TX22 / WHB telegrams expand to several records)
     assert len(recs) >= len([ln for ln in out.splitlines() if ln.strip()])
+
+
+def _three_streams(golden_dir, tmp_path):
+    from tfrec_amd import synth
+    g = json.load(open(os.path.join(golden_dir, "handler_records.json")))
+    c = g["case"]
+    files = []
+    for k in range(3):
+        iq = synth.gen_stream(c["seed"], c["stream"] + k, c["n_blocks"], c["proto_mask"], c["noise_q8"])
+        p = tmp_path / ("s%d.iq" % k)
+        iq.tofile(p)
+        files.append(str(p))
+    return g, c, files
+
+
+@pytest.mark.gpu
+def test_handler_records_equal_the_real_reference(cli, golden_dir, tmp_path):
+    """what the result sink delivers == the command lines the REAL reference's execute_handler builds
+    (decoder.cpp:67-96) after store_data's dedupe (:46-65, incl. the WHB sequence rule), for three streams in one batch;
+    -m 1: the summary of flush_storage (:98-109) in the reference's order.  Goldens: oracle/mint_handler_records.py."""
+    g, c, files = _three_streams(golden_dir, tmp_path)
+    largs = sum((["-L", f] for f in files), [])
+    base = [cli, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-q", "-b", "16"]
+    for mode in (0, 1):
+        sink = tmp_path / ("sink%d.out" % mode)
+        subprocess.run(base + ["-m", str(mode), "-E", "cat > %s" % sink] + largs, check=True)
+        recs = [ln.split() for ln in sink.read_text().splitlines()]
+        for k in range(3):
+            got = [" ".join(r[1:-1]) for r in recs if r[0] == str(k)]  # minus the stream tag and ts
+            assert got == g["streams"][k]["mode%d" % mode], (mode, k)
+    # the reference's own one-exec-per-record path on one stream
+    out = subprocess.run(base + ["-e", "echo REC", "-L", files[1]], capture_output=True, text=True, check=True).stdout
+    assert [" ".join(ln.split()[1:-1]) for ln in out.splitlines() if ln.startswith("REC ")] == g["streams"][1]["mode0"]
+
+
+@pytest.mark.gpu
+def test_streams_sharded_over_several_device_contexts(cli, golden_dir, tmp_path):
+    """SURVEY 8e on the C++ side: '-d a,b,..' = one host thread + context per entry, dump files sharded by index, events
+    concatenated on the host: stdout and the sink are those of a single-context run (two contexts on device 0 here)."""
+    g, c, files = _three_streams(golden_dir, tmp_path)
+    largs = sum((["-L", f] for f in files), [])
+    base = [cli, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-b", "7"]
+    outs = []
+    for dev in ("0", "0,0", "0,0,0"):
+        sink = tmp_path / ("sink_%s.out" % dev.replace(",", "_"))
+        o = subprocess.run(base + ["-d", dev, "-E", "cat > %s" % sink] + largs, capture_output=True, text=True, check=True).stdout
+        outs.append((o, [ln.split()[:-1] for ln in sink.read_text().splitlines()]))
+    assert len(outs[0][0].splitlines()) > 50
+    assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
+@pytest.mark.gpu
+def test_reference_linked_cli_replays_a_dump(golden_dir, tmp_path):
+    """The adapter linked with the REAL reference decoders (oracle/_ref/tfrec_gpu_ref, built where the reference tree
+    exists; it travels with the snapshot): GPU flush events -> unchanged tfa1/tfa2/whb_decoder::flush -> the reference's
+    own printf -- the text the reference prints for the same dump."""
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "tfrec_gpu_ref")
+    if not os.path.exists(ref_cli):
+        pytest.skip("oracle/_ref/tfrec_gpu_ref was not built (no reference tree at build time)")
+    from tfrec_amd import synth
+    c = json.load(open(os.path.join(golden_dir, "streams.json")))["cases"][0]
+    iq = synth.gen_stream(c["seed"], c["stream"], c["n_blocks"], c["proto_mask"], c["noise_q8"])
+    p = tmp_path / "s.iq"
+    iq.tofile(p)
+    out = subprocess.run([ref_cli, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-b", "7", "-L", str(p)],
+                         capture_output=True, text=True, check=True).stdout
+    want = [ln for ln in c["text"].splitlines() if ln != "Inverted SYNC"]
+    got = [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("WHB: Samples")]
+    assert got == want

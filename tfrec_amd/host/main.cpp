@@ -1,6 +1,6 @@
 // tfrec_amd/host/main.cpp -- tfrec_gpu: the reference's file-replay CLI on the GPU path.
 //
-//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d device] [-b blocks] [-e handler | -E handler] [-m mode]
+//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d device[,device...]] [-b blocks] [-e handler | -E handler] [-m mode]
 //             -L dump.iq [-L more.iq ...]
 //   tfrec_gpu [-T hexmask] -X telegrams.txt
 //
@@ -23,13 +23,14 @@
 
 static int replay_hex(int types, int dbg, const char *fn, const char *exec, bool batched)
 {
-	pipe_sink *sink = (batched && exec) ? new pipe_sink(exec) : NULL;
+	pipe_sink *psink = (batched && exec) ? new pipe_sink(exec) : NULL;
+	batch_sink *sink = psink;
 	std::vector<decoder *> decs;
-	if (types & (1 << TFA_1)) decs.push_back(new tfa1_decoder(TFA_1));
-	if (types & (1 << TFA_2)) decs.push_back(new tfa2_decoder(TFA_2));
-	if (types & (1 << TFA_3)) decs.push_back(new tfa2_decoder(TFA_3));
-	if (types & (1 << TX22)) decs.push_back(new tfa2_decoder(TX22));
-	if (types & (1 << TFA_WHB)) decs.push_back(new whb_decoder(TFA_WHB));
+	if (types & (1 << TFA_1)) decs.push_back(new sinked_decoder<tfa1_decoder>(TFA_1, &sink, 0));
+	if (types & (1 << TFA_2)) decs.push_back(new sinked_decoder<tfa2_decoder>(TFA_2, &sink, 0));
+	if (types & (1 << TFA_3)) decs.push_back(new sinked_decoder<tfa2_decoder>(TFA_3, &sink, 0));
+	if (types & (1 << TX22)) decs.push_back(new sinked_decoder<tfa2_decoder>(TX22, &sink, 0));
+	if (types & (1 << TFA_WHB)) decs.push_back(new sinked_decoder<whb_decoder>(TFA_WHB, &sink, 0));
 	FILE *fd = fopen(fn, "r");
 	if (!fd) {
 		perror("Can't open message file");
@@ -45,8 +46,6 @@ static int replay_hex(int types, int dbg, const char *fn, const char *exec, bool
 			buf[len++] = (uint8_t)strtol(tok, NULL, 16);
 		for (size_t k = 0; k < decs.size(); k++) {
 			decs[k]->set_params(batched ? NULL : (char *)exec, 0, dbg);
-			if (sink)
-				decs[k]->set_sink(sink, 0);
 			decs[k]->store_bytes(buf, len);
 			decs[k]->flush(0);
 			puts("");
@@ -54,13 +53,14 @@ static int replay_hex(int types, int dbg, const char *fn, const char *exec, bool
 		}
 	}
 	fclose(fd);
-	delete sink;  // flushes
+	delete psink;  // flushes
 	return 0;
 }
 
 int main(int argc, char **argv)
 {
-	int types = 0x07, thresh = 0, filter = 0, dbg = 0, device = 0, blocks = 16;  // defaults of main.cpp:97-105 (0 = auto)
+	int types = 0x07, thresh = 0, filter = 0, dbg = 0, blocks = 16;  // defaults of main.cpp:97-105 (0 = auto)
+	std::vector<int> devices;
 	std::vector<std::string> dumps;
 	const char *hexfile = NULL, *exec = NULL;
 	bool batched = false;
@@ -73,7 +73,10 @@ int main(int argc, char **argv)
 		case 'W': filter = 1; break;
 		case 'q': dbg = -1; break;
 		case 'D': dbg++; break;
-		case 'd': device = atoi(optarg); break;
+		case 'd':  // one ordinal or a comma-separated list: the dump files are sharded over the devices by index
+			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ","))
+				devices.push_back(atoi(tok));
+			break;
 		case 'b': blocks = atoi(optarg); break;
 		case 'L': dumps.push_back(optarg); break;
 		case 'X': hexfile = optarg; break;
@@ -96,7 +99,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "tfrec_gpu: -t must be >= 0 (0 = auto)\n");
 		return 1;
 	}
-	gpu_engine e(dumps, types, thresh, filter, dbg, device, blocks);
+	gpu_engine e(dumps, types, thresh, filter, dbg, devices, blocks);
 	if (exec || mode)
 		e.set_handler(exec, batched, mode);
 	int rc = e.run();

@@ -1,9 +1,9 @@
 // tfrec_amd/host/plugin.h -- host-side mirror of the reference's plugin surface for the hot path.
 //
-// Same class names, virtuals, members and call conventions as baycom/tfrec's decoder.h:21-73, so that
-//   * the reference's own protocol handlers (tfa1_decoder, tfa2_decoder, whb_decoder) could be linked against
-//     this header unchanged, and
-//   * code written against the reference (register a decoder, feed it, read sensordata_t) ports 1:1.
+// Same class names, virtuals, members and call conventions as baycom/tfrec's decoder.h:21-73: the adapter
+// (gpu_engine.cpp, main.cpp) uses nothing else, so it compiles unchanged against the reference's OWN headers and links
+// with the reference's own decoder objects (-DTFREC_AMD_REFERENCE_PLUGINS, tests/test_reference_link_cpu.py) -- this
+// mirror only exists because the reference's sources do not travel to the GPU box.
 // The implementations in this directory are written from the protocol documentation and the behaviour
 // pinned by tests/golden (not copied); see INTEGRATION.md for the adapter contract.
 #ifndef TFREC_AMD_HOST_PLUGIN_H
@@ -39,16 +39,6 @@ typedef struct {
 	int rssi;
 } sensordata_t;
 
-// Batched result sink.  The reference runs system("<handler> <args>") once per telegram
-// (decoder.cpp:67-96): one fork+exec per record does not scale to thousands of streams.  A decoder that has a sink
-// hands the SAME argument string (id temp hum seq alarm rssi flags ts) to it instead, tagged with its stream; the
-// engine flushes the sink once per batch (gpu_engine.cpp: one long-lived handler process fed through a pipe).
-class batch_sink {
-public:
-	virtual ~batch_sink() {}
-	virtual void put(int stream, const char *args) = 0;
-};
-
 // decoder.h:33-59
 class decoder {
 public:
@@ -64,8 +54,6 @@ public:
 	int count(void) { return (int)data.size(); }
 	sensor_e get_type(void) { return type; }
 	virtual void store_bytes(uint8_t *d, int len);
-	// not in the reference: route execute_handler() to a batch sink (records are tagged with `stream`)
-	void set_sink(batch_sink *s, int stream) { sink = s; sink_stream = stream; }
 
 protected:
 	int dbg;
@@ -79,8 +67,6 @@ private:
 	char *handler;
 	int mode;
 	std::map<uint64_t, sensordata_t> data;
-	batch_sink *sink;
-	int sink_stream;
 };
 
 // decoder.h:61-73.  On the GPU path the demodulators run in HIP; this class only keeps the (decoder*)

@@ -15,7 +15,7 @@
 
 // ---------------------------------------------------------------- decoder base (decoder.cpp:9-109)
 decoder::decoder(sensor_e _type)
-	: dbg(0), bad(0), synced(0), type(_type), byte_cnt(0), handler(NULL), mode(0), sink(NULL), sink_stream(0)
+	: dbg(0), bad(0), synced(0), type(_type), byte_cnt(0), handler(NULL), mode(0)
 {
 	memset(rdata, 0, sizeof(rdata));
 }
@@ -65,7 +65,7 @@ void decoder::store_data(sensordata_t &d)
 // handler command line: cmd id temp hum seq alarm rssi flags ts (decoder.cpp:67-96)
 void decoder::execute_handler(sensordata_t &d)
 {
-	if (!sink && (!handler || !*handler))
+	if (!handler || !*handler)
 		return;
 	char args[384];
 	if (type != TFA_WHB)
@@ -74,10 +74,6 @@ void decoder::execute_handler(sensordata_t &d)
 	else
 		snprintf(args, sizeof(args), "%013" PRIx64 " %+.1f %g %i %i %i %i %li", d.id, d.temp, d.humidity, d.sequence, d.alarm,
 			 d.rssi, d.flags, (long)d.ts);
-	if (sink) {  // batched: the engine delivers the records of a whole batch at once
-		sink->put(sink_stream, args);
-		return;
-	}
 	char cmd[512];
 	snprintf(cmd, sizeof(cmd), "%s %s", handler, args);
 	if (dbg >= 1)
