@@ -61,6 +61,11 @@ enum {
 				      block and stream); a 10:1 decimating FIR in the reference's integer style (60 int16
 				      taps, >>16 per tap, int16 store; defined in DESIGN.md, no reference counterpart)
 				      produces the 1.536 MS/s int16 stream that enters downconvert::process_iq */
+#define TFREC_AMD_F_BITS 16u        /* parity/debug: besides the flush events, report every bit the demodulators hand to
+				      decoder::store_bit (decoder.h:39; tfa1.cpp:120, tfa2.cpp:281, whb.cpp:566) as BITS events: status
+				      = TFREC_AMD_STATUS_BITS, byte_cnt = bits in this chunk (<= 512), rdata = the bits, LSB first,
+				      seq = ordinal of the flush they precede, (end_sample, offset) = their order within that flush.
+				      Window-parallel pipeline only. */
 #define TFREC_AMD_F_SERIAL_CHAINS 4u /* run the demodulators as one serial lane per (stream, slot) -- the simple
 				      GPU formulation kept as a cross-check of the window-parallel pipeline */
 
@@ -75,6 +80,8 @@ typedef struct {
 	int32_t max_events;  /* device event buffer capacity per submit/drain cycle */
 	uint32_t flags;      /* TFREC_AMD_F_* */
 } tfrec_amd_config;
+
+#define TFREC_AMD_STATUS_BITS 0x80 /* event.status of a BITS chunk (TFREC_AMD_F_BITS) */
 
 /* One decoder::flush() call site (tfa1.cpp:180, tfa2.cpp:434, whb.cpp:696).  96 bytes. */
 typedef struct {

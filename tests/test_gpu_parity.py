@@ -371,3 +371,83 @@ def test_fm_dev_slow_path_through_the_pipeline(eps, monkeypatch):
         st = r.fm_stats()
         assert st["resolved"] > 30 and st["host_verified"] > 30 and st["host_mismatch"] == 0
         assert st["undecidable"] == 0
+
+
+@pytest.mark.parametrize("splits", [1, 3])
+def test_bits_mode_every_store_bit_equals_the_oracle(splits):
+    """SURVEY 8b 'kind = BITS': with TFREC_AMD_F_BITS every bit the demodulators hand to decoder::store_bit (tfa1.cpp:120,
+    tfa2.cpp:281 incl. the 16 trailing bits, whb.cpp:566 incl. the 16 zeros before a flush) comes back, grouped by the
+    flush it precedes; compared flush by flush with the oracle's bit log (= the real reference's 'W' records,
+    tests/test_oracle_golden.py) for all five slots, also when the stream is cut into several submits."""
+    n_streams, n_blocks = 5, 24
+    iq = synth.gen_batch(43, 3, n_streams, n_blocks)
+    cut = n_blocks // splits
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=cut, all_flushes=True, bits=True, max_events=1 << 17) as r:
+        evs = []
+        for k in range(splits):
+            r.submit(np.ascontiguousarray(iq[:, k * cut * 65536:(k + 1) * cut * 65536]))
+            evs.append(r.drain())
+        ev = np.concatenate(evs)
+    n_bits = 0
+    for s in range(n_streams):
+        o = O.Oracle(0x2F, 500, 0, log_bits=True)
+        o.process(iq[s])
+        want = {}
+        for ln in o.bits_text().splitlines():  # "W slot nbits bits": one record per flush, in flush order
+            p = ln.split()
+            want.setdefault(int(p[1]), []).append(p[3] if len(p) > 3 else "")
+        got = api.bits_by_flush(ev, s)
+        check_stream(ev, s, o)  # the flush events themselves are unchanged by the mode
+        for slot, recs in want.items():
+            for seq, bits in enumerate(recs):
+                assert got.get((slot, seq), "") == bits, "stream %d slot %d flush %d" % (s, slot, seq)
+                n_bits += len(bits)
+        assert sorted(want.keys()) == [0, 1, 2, 3, 4]
+    assert n_bits > 20000
+
+
+def _all_streams_equal(ev, iq, types, thresh, all_flushes=True):
+    """every stream of the batch against the oracle (OpenMP, one receiver per stream): vectorised comparison"""
+    orc = O.process_many(iq, types, thresh, 0)
+    gs, gm = api.events_canon(ev)
+    order = np.argsort(gs, kind="stable")  # (several drains concatenated: each is ordered by stream)
+    gs, gm = gs[order], gm[order]
+    bounds = np.searchsorted(gs, np.arange(len(iq) + 1))
+    minb = np.array([10, 7, 7, 7, 11])
+    total = 0
+    for s in range(len(iq)):
+        e = orc[s]
+        if not all_flushes:
+            e = e[(e["byte_cnt"] >= minb[e["slot"]]) & ~((e["slot"] == 3) & (e["byte_cnt"] >= 64)) & ~((e["slot"] == 4) & (e["byte_cnt"] > 60))]
+        wm = O.canon(e)
+        wm = wm[np.lexsort((wm[:, 1], wm[:, 0]))]
+        g = gm[bounds[s]:bounds[s + 1]]
+        g = g[np.lexsort((g[:, 1], g[:, 0]))]
+        assert g.shape == wm.shape and np.array_equal(g, wm), "stream %d" % s
+        total += len(wm)
+    return total
+
+
+def test_config1_single_stream_tfa123_48_blocks():
+    """BASELINE configs[1], exact shape: ONE 1.536 MS/s stream, TFA_1/2/3 concurrent (-T 7), 48 blocks -- every flush."""
+    iq = synth.gen_batch(77, 5, 1, 48)
+    with api.Receiver(1, 0x07, 500, 0, max_blocks=48, all_flushes=True) as r:
+        r.submit(iq)
+        ev = r.drain()
+        assert _all_streams_equal(ev, iq, 0x07, 500) > 30
+        assert sorted(set(ev["slot"].tolist())) == [0, 1, 2]
+        assert r.fm_stats()["host_mismatch"] == 0
+
+
+def test_quarter_of_config2_every_stream_against_the_oracle():
+    """256 streams x 48 blocks x all five protocols (a quarter of BASELINE configs[2]; bench.py's gate checks all 1024 on
+    every run): EVERY stream's complete flush log against the oracle, two submits (24 + 24 blocks) in flight."""
+    n_streams, n_blocks = 256, 48
+    iq = synth.gen_batch(1000, 0, n_streams, n_blocks)
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=24, all_flushes=True, max_events=n_streams * 24 * 40) as r:
+        r.submit(np.ascontiguousarray(iq[:, :24 * 65536]))
+        r.submit(np.ascontiguousarray(iq[:, 24 * 65536:]))
+        ev = np.concatenate([r.drain(), r.drain()])
+        total = _all_streams_equal(ev, iq, 0x2F, 500)
+        assert total > 80 * n_streams
+        assert r.fm_stats()["host_mismatch"] == 0

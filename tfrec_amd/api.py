@@ -23,6 +23,8 @@ F_ALL_FLUSHES = 1
 F_TIMING = 2
 F_SERIAL_CHAINS = 4
 F_INPUT_10X = 8
+F_BITS = 16
+STATUS_BITS = 0x80
 
 E_OK, E_INVAL, E_NOMEM, E_HIP, E_OVERFLOW, E_STATE = 0, -1, -2, -3, -4, -5
 
@@ -161,12 +163,12 @@ class Receiver:
 
     def __init__(self, n_streams: int, types_mask: int = 0x2F, thresh: int = 500, filter_type: int = 0,
                  device: int = 0, max_blocks: int = 48, max_events: int | None = None, all_flushes: bool = False,
-                 timing: bool = False, serial_chains: bool = False, input_10x: bool = False):
+                 timing: bool = False, serial_chains: bool = False, input_10x: bool = False, bits: bool = False):
         self.L = load_library()
         if max_events is None:
             max_events = max(4096, n_streams * max_blocks * 4 * (8 if all_flushes else 2))
         flags = ((F_ALL_FLUSHES if all_flushes else 0) | (F_TIMING if timing else 0)
-                 | (F_SERIAL_CHAINS if serial_chains else 0) | (F_INPUT_10X if input_10x else 0))
+                 | (F_SERIAL_CHAINS if serial_chains else 0) | (F_INPUT_10X if input_10x else 0) | (F_BITS if bits else 0))
         self.block_bytes = BLOCK_BYTES * (10 if input_10x else 1)
         self.cfg = Config(n_streams, types_mask, thresh, filter_type, device, max_blocks, max_events, flags)
         self.h = C.c_void_p()
@@ -283,6 +285,8 @@ def events_canon(events: np.ndarray):
     end_sample, byte_cnt, rssi_db, offset, rdata) -- the layout of oracle.canon()."""
     L = load_library()
     m = np.empty((len(events), 69), dtype=np.int64)
+    events = events[events["status"] != STATUS_BITS]
+    m = np.empty((len(events), 69), dtype=np.int64)
     m[:, 0] = events["slot"]
     m[:, 1] = events["end_sample"]
     m[:, 2] = events["byte_cnt"]
@@ -294,13 +298,27 @@ def events_canon(events: np.ndarray):
     return events["stream"].astype(np.int64), m
 
 
+def bits_by_flush(events: np.ndarray, stream: int):
+    """TFREC_AMD_F_BITS: {(slot, seq): "0110..."} -- the bits handed to decoder::store_bit before flush number seq of the
+    slot, from the BITS chunks of `events` (drain order; concatenate the drains of consecutive submits first)."""
+    out = {}
+    for e in events:
+        if int(e["stream"]) != stream or int(e["status"]) != STATUS_BITS:
+            continue
+        n = int(e["byte_cnt"])
+        bits = np.unpackbits(e["rdata"], bitorder="little")[:n]
+        key = (int(e["slot"]), int(e["seq"]))
+        out[key] = out.get(key, "") + "".join("01"[b] for b in bits)
+    return out
+
+
 def event_tuples(events: np.ndarray, stream: int | None = None):
     """Canonical comparable form (slot, end_sample, byte_cnt, rssi_db, offset, rdata) of flush events,
     in per-(stream, slot) order -- the same tuple the oracle and the reference harness produce."""
     L = load_library()
     out = []
     for e in events:
-        if stream is not None and int(e["stream"]) != stream:
+        if (stream is not None and int(e["stream"]) != stream) or int(e["status"]) == STATUS_BITS:
             continue
         out.append((int(e["slot"]), int(e["end_sample"]), int(e["byte_cnt"]),
                     int(L.tfrec_amd_rssi_db(int(e["slot"]), int(e["rssi_raw"]))), int(e["offset"]),

@@ -801,7 +801,15 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 			return a.stream < b.stream;
 		if (a.slot != b.slot)
 			return a.slot < b.slot;
-		return a.seq < b.seq;
+		if (a.seq != b.seq)
+			return a.seq < b.seq;
+		// TFREC_AMD_F_BITS: the bit chunks of a flush come before it, in the order the bits were produced
+		const bool ab = a.status == TFREC_AMD_STATUS_BITS, bb = b.status == TFREC_AMD_STATUS_BITS;
+		if (ab != bb)
+			return ab;
+		if (a.end_sample != b.end_sample)
+			return a.end_sample < b.end_sample;
+		return a.offset < b.offset;
 	});
 	uint32_t ncopy = have;
 	if (ncopy > (uint32_t)cap) {

@@ -1683,6 +1683,37 @@ __device__ __forceinline__ void whb_commit_stream(int s, int n_streams, int n_bl
 		d.psk ^= (fl & kWhbFPsk) ? 1 : 0;
 		d.last_psk = d.psk;
 		d.lfsr = wd->lfsr;
+		if (flags & TFREC_AMD_F_BITS) {  // parity mode: the runs "0,1,1,.." (and the 16 zeros before a flush) as bits
+			const int og = T.open[(size_t)c * T.cap + j];
+			const uint16_t *e16 = reinterpret_cast<const uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
+			uint32_t words[16];
+			int nb = 0, chunk = 0;
+			auto put = [&](int bit) {
+				if ((nb & 31) == 0)
+					words[nb >> 5] = 0u;
+				words[nb >> 5] |= (uint32_t)bit << (nb & 31);
+				if (++nb == 512) {
+					emit_bits(e, d.seq, og, chunk, words, 512);
+					chunk++;
+					nb = 0;
+				}
+			};
+			for (int q = 0; q < rr->nbits;) {
+				int len = e16[q++];
+				if (len == kWhbRunEsc) {
+					len = (int)((uint32_t)e16[q] | ((uint32_t)e16[q + 1] << 16));
+					q += 2;
+				}
+				put(0);
+				for (int m = 1; m < len; m++)
+					put(1);
+			}
+			if (rr->closed)
+				for (int z = 0; z < 16; z++)
+					put(0);
+			if (nb)
+				emit_bits(e, d.seq, og, chunk, words, nb);
+		}
 		if (rr->closed) {  // whb.cpp:693-697
 			const long long rssi =
 				(long long)((unsigned long long)(uint32_t)rr->rssi_i | ((unsigned long long)(uint32_t)rr->offset << 32));
@@ -2365,6 +2396,8 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 		d.sr_cnt = wd->sr_cnt;
 		d.byte_cnt = wd->byte_cnt;
 		d.invert = wd->invert;
+		if ((flags & TFREC_AMD_F_BITS) && rr->nbits > 0)  // parity mode: what the slicer handed to store_bit in this window
+			emit_bits(e, d.seq, og, 0, win_bits(T, c, j, og), rr->nbits);
 		if (rr->closed)  // the window's timeout fired: decoder::flush
 			flush<KIND>(e, d, rr->rssi_i, KIND == 1 ? rr->offset : 0, last);
 		last_r = rr;

@@ -101,6 +101,38 @@ struct EmitCtx {
 	bool quiet = false;  // compute everything, report nothing (the non-leading lanes of a wave-per-chain kernel)
 };
 
+// TFREC_AMD_F_BITS: `nbits` bits (LSB first in words[]) that precede flush number `seq` of this (stream, slot), as chunks
+// of up to 512; `g_open` (the window's first sample) places them among the other bits of the same flush, the chunk index
+// (from chunk0 on) goes to `offset`
+__device__ inline void emit_bits(const EmitCtx &e, uint32_t seq, int g_open, int chunk0, const uint32_t *words, int nbits)
+{
+	if (e.quiet)
+		return;
+	for (int b0 = 0, chunk = chunk0; b0 < nbits; b0 += 512, chunk++) {
+		const int n = nbits - b0 < 512 ? nbits - b0 : 512;
+		const uint32_t idx = atomicAdd(&e.eb->count, 1u);
+		if (idx >= e.eb->capacity)
+			continue;
+		tfrec_amd_event *ev = e.events + idx;
+		ev->stream = e.stream;
+		ev->slot = (uint8_t)e.slot;
+		ev->status = (uint8_t)TFREC_AMD_STATUS_BITS;
+		ev->byte_cnt = (uint16_t)n;
+		ev->offset = chunk;
+		ev->seq = seq;
+		ev->end_sample = e.sample_base + g_open;
+		ev->rssi_raw = 0;
+		uint32_t *dst = reinterpret_cast<uint32_t *>(ev->rdata);
+		for (int w = 0; w < 16; w++) {
+			const int bw = b0 + 32 * w;
+			uint32_t v = bw < nbits ? words[bw >> 5] : 0u;
+			if (bw < nbits && nbits - bw < 32)
+				v &= (1u << (nbits - bw)) - 1u;
+			dst[w] = v;
+		}
+	}
+}
+
 // one lane's working copy of the decoder (registers) + its rdata in global memory
 struct Dec {
 	uint32_t sr;
