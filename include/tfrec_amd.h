@@ -131,7 +131,10 @@ int tfrec_amd_destroy(tfrec_amd_ctx *ctx);
  * the work is ordered after what is already queued on hip_stream (a hipStream_t, NULL = default stream) -- the
  * producer of d_iq -- and runs on the context's own streams; d_iq must stay valid until the submit has been
  * drained (or tfrec_amd_sync returned).  All demodulator/decoder state carries over to the next submit exactly as
- * it carries from block to block in the reference. */
+ * it carries from block to block in the reference.
+ * A HIP failure in the middle of a submit (TFREC_AMD_E_HIP after work was enqueued) poisons the context: kernels may
+ * already have advanced the carried state, so every later submit / drain returns TFREC_AMD_E_STATE until the context is
+ * destroyed and recreated.  Argument errors (E_INVAL, a full FIFO) leave it untouched. */
 int tfrec_amd_submit_device(tfrec_amd_ctx *ctx, const void *d_iq, size_t stream_stride_bytes, int n_blocks,
 			    void *hip_stream);
 /* Same with host memory: stages the batch through an internal device buffer (H2D copy included).  With pinned
@@ -150,7 +153,8 @@ int tfrec_amd_sync(tfrec_amd_ctx *ctx);
  * (tfa2.cpp:434) and whb_demod::demod (whb.cpp:696): one tfrec_amd_event per call site and window.
  * Wait for the OLDEST submit that has not been drained yet, then copy its events to out[0..cap), ordered by
  * (stream, slot, seq).  *n_out = number written (0 if nothing was submitted).  Returns TFREC_AMD_E_OVERFLOW if the
- * device buffer or cap was too small (the events that fit are still returned).
+ * device buffer or cap was too small (the events that fit are still returned; the others are lost -- the decoder state and
+ * the flush ordinals `seq` move on, so a gap in seq shows where).
  * Submits and drains form a FIFO of depth TFREC_AMD_FIFO_DEPTH (3): a caller may queue submits k+1 and k+2 before
  * draining submit k, so that the GPU works on them (front end of k+2, filter stage of k+1 and slicer/decoder stage of
  * k run beside each other) while the host copies and dispatches k's events; one more undrained submit is refused

@@ -128,7 +128,24 @@ struct tfrec_amd_ctx {
 	// error bound; TFREC_AMD_FM_FLAG_EPS (tests) widens it to drive the slow path -- exact for any value -- through the
 	// pipeline with ordinary input: 1e-3 fills the deferred list, 0.6 overflows it (every sample: the rescan path)
 	double fm_flag_eps = 1e-9;
+	// A HIP call failed in the middle of a submit: kernels of it may already have run on carried state (FIR history, chain
+	// state, the FIFO's bookkeeping), so the context cannot continue exactly.  Every later submit / drain returns
+	// TFREC_AMD_E_STATE; destroy and recreate.
+	bool poisoned = false;
 };
+
+namespace {
+struct PoisonGuard {
+	tfrec_amd_ctx *c;
+	bool ok = false;
+	explicit PoisonGuard(tfrec_amd_ctx *c_) : c(c_) {}
+	~PoisonGuard()
+	{
+		if (!ok)
+			c->poisoned = true;
+	}
+};
+}  // namespace
 
 // ---- biquad coefficients (iir2::set, dsp_stuff.cpp:36-45) in the arithmetic of the reference's normative
 // build (oracle/tfrec_oracle.c header).  The five cut-offs the reference ever instantiates
@@ -604,7 +621,12 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		snprintf(g_err, sizeof(g_err), "%d submits are waiting to be drained: call tfrec_amd_drain_events first", kSets);
 		return TFREC_AMD_E_STATE;
 	}
+	if (c->poisoned) {
+		snprintf(g_err, sizeof(g_err), "an earlier submit failed half way: the context must be recreated");
+		return TFREC_AMD_E_STATE;
+	}
 	HIPCHK(hipSetDevice(c->cfg.device));
+	PoisonGuard guard(c);  // from here on work is enqueued: a failure leaves the carried state undefined
 	const bool timing = (c->cfg.flags & TFREC_AMD_F_TIMING) != 0;
 	const int set = (c->head + c->inflight) % kSets;  // this submit's event buffers and timing events
 	// Front end on its own stream: it starts when the caller's stream has produced the input, and may overlap the
@@ -682,6 +704,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	c->tail_sel ^= 1;
 	c->sample_base += (long long)n_blocks * kBlockDec;
 	c->last_blocks = n_blocks;
+	guard.ok = true;
 	return TFREC_AMD_OK;
 }
 
@@ -765,6 +788,10 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	if (!c || !n_out || cap < 0 || (cap > 0 && !out))
 		return TFREC_AMD_E_INVAL;
 	*n_out = 0;
+	if (c->poisoned) {
+		snprintf(g_err, sizeof(g_err), "an earlier submit failed half way: the context must be recreated");
+		return TFREC_AMD_E_STATE;
+	}
 	if (c->inflight == 0)
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
