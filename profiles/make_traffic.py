@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel LAUNCH from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace domains).
 usage: make_traffic.py <fetch_dir> <write_dir> <out.json> <streams> <blocks> <types>
-hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts half of the bytes of a 16 B/lane stream
-(MI355X_MICROARCH.md, HBM section); check: frontend_kernel reads 2*1.62 GB = 3.3 GB vs 3.22 GB of input."""
+hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE counts half of the bytes read (MI355X_MICROARCH.md, HBM
+section), for every access pattern of this project -- calibrated with known-byte kernels, profiles/r02_hbm_calibration.json:
+16 / 4 / 2 B per lane coalesced: x2.00, lane-per-row 16 B loads (the biquad passes): x1.90 (5 % over-fetch); WRITE_SIZE is
+exact for coalesced stores of any width and reports 2.76x the bytes of lane-per-row 16 B stores (partial-line writes:
+real extra traffic).  total_hbm_bytes_per_batch = sum over kernels of hbm_bytes x launches per batch (one batch = one
+frontend launch)."""
 import collections, csv, glob, json, sys
 
 
@@ -30,5 +34,13 @@ for k in sorted(fetch):
         continue
     out["kernels"][k] = {"fetch_size_kb_raw": round(fetch[k], 1), "write_size_kb_raw": round(write.get(k, 0.0), 1),
                          "hbm_bytes": int((2 * fetch[k] + write.get(k, 0.0)) * 1024), "dispatches_profiled": n[k]}
+nb = max(1, n.get("frontend_kernel", 1))
+total = 0
+for k, v in out["kernels"].items():
+    v["launches_per_batch"] = round(v["dispatches_profiled"] / nb, 2)
+    total += v["hbm_bytes"] * v["dispatches_profiled"] / nb
+out["total_hbm_bytes_per_batch"] = int(total)
+out["algorithmic_bytes_per_batch"] = 2 * int(sys.argv[4]) * int(sys.argv[5]) * 32768
+out["traffic_ratio"] = round(total / out["algorithmic_bytes_per_batch"], 3)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
