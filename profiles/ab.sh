@@ -12,7 +12,7 @@ for r in $(seq $rounds); do
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = j['roofline']['kernels_ms']
-top = sorted(k.items(), key=lambda kv: -kv[1])[:4]
+top = sorted(k.items(), key=lambda kv: -kv[1])[:9]
 print('%-28s %7.3f ms/step (min %.2f med %.2f)  %s' % ('$(basename $lib)', j['ms_per_step'], j['ms_min'], j['ms_median'], ' '.join('%s=%.2f' % (a.replace('_kernel',''), b) for a, b in top)))
 "
 	done

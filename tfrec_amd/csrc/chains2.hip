@@ -1288,7 +1288,28 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 					break;
 				const int k = __builtin_ctzll(m);
 				todo = k >= 63 ? 0ull : (~0ull << (k + 1));
+				const int lb0 = last_bit;
 				candidate(gb + k, last_bit ^ 1);
+				// A RUN of candidates of the same polarity right behind a candidate that did not flip last_bit (a glitch, or
+				// an edge out of the timing window; the other protocols' bursts and noise produce them every few samples):
+				// none of them can be accepted.  After sample k, index - lbi is at most 4 at the next sample, grows by 2 per
+				// sample and falls back to 0 whenever it exceeds 2 ("if (index - lbi > 2) lbi = index", tfa2.cpp:410-411): it
+				// never exceeds 8 (:391), so the run only moves last_bit_idx -- to the last sample at which that rule fired.
+				// O(1) instead of a walk over every sample of the run (within one block: the indices restart at a block's start).
+				if (last_bit == lb0 && k < 63) {
+					const unsigned long long rest = m >> (k + 1);
+					int R = rest == ~0ull ? 63 - k : __builtin_ctzll(~rest);  // candidates at k+1 .. k+R
+					const int room = (kBlockDec - 1) - ((gb + k) & (kBlockDec - 1));  // samples left in this block
+					R = R < room ? R : room;
+					if (R > 0) {
+						const int index_k = 2 * ((gb + k) & (kBlockDec - 1));
+						const int e = index_k + 2 - lbi;  // index - lbi at sample k + 1 (<= 4)
+						const int t_set = e > 2 ? 1 : ((2 - e) >> 1) + 2;  // first sample of the run at which the rule fires
+						if (t_set <= R)
+							lbi = index_k + 2 * (t_set + 2 * ((R - t_set) >> 1));
+						todo = k + R >= 63 ? 0ull : (~0ull << (k + R + 1));
+					}
+				}
 			}
 			continue;
 		}
