@@ -451,3 +451,56 @@ def test_quarter_of_config2_every_stream_against_the_oracle():
         total = _all_streams_equal(ev, iq, 0x2F, 500)
         assert total > 80 * n_streams
         assert r.fm_stats()["host_mismatch"] == 0
+
+
+def test_hostile_and_degenerate_inputs_over_ragged_submits():
+    """Inputs a receiver must survive, each against the oracle, in one batch cut into submits of 1, 2, 5 and 3 blocks: pure
+    silence (no window at all), full-scale DC (0x00 / 0xff: the trigger never releases, the discriminator sits on its
+    axis / diagonal constants), uniform random bytes (every demodulator's window open for the whole stream, garbage
+    bits, a window that spans all submits), a periodic pattern (one discriminator direction repeated), a real burst
+    stream, and a stream that goes silent half way."""
+    n_blocks = 11
+    rng = np.random.default_rng(5)
+    good = synth.gen_batch(61, 0, 2, n_blocks)
+    n = good.shape[1]
+    rows = [np.full(n, 0x80, np.uint8), np.zeros(n, np.uint8), np.full(n, 0xFF, np.uint8),
+            rng.integers(0, 256, n, dtype=np.uint8), np.tile(np.array([0x90, 0x70, 0x60, 0xA0, 0x85, 0x7B], np.uint8), n // 6 + 1)[:n],
+            good[0], good[1].copy()]
+    rows[6][n // 2:] = 0x80
+    iq = np.stack(rows)
+    cuts = [0, 1, 3, 8, 11]
+    with api.Receiver(len(iq), 0x2F, 500, 0, max_blocks=5, all_flushes=True, max_events=1 << 16) as r:
+        evs = []
+        for a, b in zip(cuts, cuts[1:]):
+            r.submit(np.ascontiguousarray(iq[:, a * 65536:b * 65536]))
+            evs.append(r.drain())
+        ev = np.concatenate(evs)
+        for s in range(len(iq)):
+            o = oracle_events(iq[s], 0x2F, 500)
+            check_stream(ev, s, o)
+            want_dec = np.empty(2 * n_blocks * 8192, dtype=np.int16)
+        assert len(api.event_tuples(ev, 0)) == 0  # silence: nothing at all
+        assert r.fm_stats()["host_mismatch"] == 0
+
+
+def test_event_buffer_overflow_is_reported_and_the_context_goes_on():
+    """max_events too small: drain returns the events that fit with TFREC_AMD_E_OVERFLOW (include/tfrec_amd.h); state and
+    flush ordinals move on, so the next submit's events are the oracle's again."""
+    n_streams, n_blocks = 4, 16
+    iq = synth.gen_batch(62, 0, n_streams, n_blocks)
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=8, all_flushes=True, max_events=16) as r:
+        r.submit(np.ascontiguousarray(iq[:, :8 * 65536]))
+        with pytest.raises(api.TfrecAmdError) as ei:
+            r.drain()
+        assert ei.value.code == api.E_OVERFLOW
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=8, all_flushes=True, max_events=16) as r:
+        r.submit(np.ascontiguousarray(iq[:, :8 * 65536]))
+        first = r.drain(allow_overflow=True)
+        assert len(first) == 16
+    # (a context with room: the reference for the second half's events)
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=8, all_flushes=True) as r:
+        r.submit(np.ascontiguousarray(iq[:, :8 * 65536]))
+        r.submit(np.ascontiguousarray(iq[:, 8 * 65536:]))
+        ev = np.concatenate([r.drain(), r.drain()])
+        for s in range(n_streams):
+            check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
