@@ -137,6 +137,8 @@ def main():
                     help="backend of the barrier / scalar reduces at N>1 (the data path has no collective)")
     ap.add_argument("--same-device", action="store_true", help="tests: every rank uses cuda:0")
     ap.add_argument("--h2d-steps", type=int, default=4, help="batches of the PCIe-inclusive leg (0 = skip; N=1 only)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short secondary measurements of BASELINE configs[1] and configs[4] (N=1 only)")
     ap.add_argument("--depth", type=int, default=3, help="batches kept in the submit/drain FIFO (1..3)")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
@@ -302,6 +304,61 @@ def main():
         except Exception as e:  # the leg is informative: never fail the line for it
             h2d = dict(error=str(e)[:200])
 
+    # ---- secondary, short measurements of the other single-GPU configurations of BASELINE.json (never `value`): same
+    # method (input resident in HBM, FIFO of depth 3, parity gate on fresh state against the oracle)
+    extra = {}
+    if world == 1 and not a.no_extra_configs and not a.input_10x and (n_streams, n_blocks, a.types) == (1024, 48, 0x2F):
+        from oracle import oracle as O
+
+        def side(name, xs, xb, xt, x10, steps):
+            xr = 10 if x10 else 1
+            xu = min(xs, 16)
+            if x10:
+                xh = np.stack([synth.gen_stream(2000, k, xb, 0x1F, 256, rate_mult=10) for k in range(xu)])
+            else:
+                xh = synth.gen_batch(2000, 0, xu, xb)
+            xd = torch.empty((xs, xb * api.BLOCK_BYTES * xr), dtype=torch.uint8, device=dev)
+            xdu = torch.from_numpy(xh).to(dev)
+            for s0 in range(0, xs, xu):
+                xd[s0:s0 + min(xu, xs - s0)].copy_(xdu[:min(xu, xs - s0)])
+            with api.Receiver(xs, xt, a.thresh, 0, device=dev_index, max_blocks=xb, max_events=max(4096, xs * 256),
+                              input_10x=x10) as xr_:
+                xr_.submit(xd)
+                first = xr_.drain()
+                ok = True
+                minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
+                for k in range(min(2, xu)):
+                    o = O.Oracle(xt, a.thresh, 0)
+                    if x10:
+                        o.process_s16(O.decim10(xh[k]))
+                    else:
+                        o.process(xh[k])
+                    want = sorted(e for e in o.events() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
+                                  and not (e[0] == 4 and e[2] > 60))
+                    ok = ok and sorted(api.event_tuples(first, k)) == want
+                q = 0
+                for k in range(3):  # warm-up
+                    xr_.submit(xd)
+                    xr_.drain()
+                torch.cuda.synchronize(dev)
+                tx = time.perf_counter()
+                for k in range(steps):
+                    while q < steps and q - k < depth:
+                        xr_.submit(xd)
+                        q += 1
+                    xr_.drain()
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - tx
+            extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, input_10x=x10, steps=steps, parity_ok=ok,
+                               ms_per_step=round(dt / steps * 1e3, 4),
+                               value=round(xs * xb * SAMPLES_PER_BLOCK * xr * steps / dt / 1e6, 1), unit="MSamples/s")
+
+        try:
+            side("configs[1]: one 1.536 MS/s stream, TFA_1/2/3 (-T 7)", 1, 48, 0x07, False, 30)
+            side("configs[4]: 256 streams at 15.36 MS/s through the 10:1 front end, all five protocols", 256, 48, 0x2F, True, 8)
+        except Exception as e:  # informative legs: never fail the line for them
+            extra["error"] = str(e)[:200]
+
     samples_per_step_gpu = n_streams * n_blocks * SAMPLES_PER_BLOCK * rate  # complex INPUT samples
     total_samples = samples_per_step_gpu * a.steps * world
     value = total_samples / elapsed / 1e6
@@ -371,6 +428,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host[: min(unique, 256)], a.types, a.thresh, a.cpu_budget)
         if h2d is not None:
             out["h2d_included"] = h2d
+        if extra:
+            out["other_configs"] = extra
         print(json.dumps(out), flush=True)
     r.close()
     if fm_bad:
