@@ -466,6 +466,46 @@ __device__ __forceinline__ void k3_store(void *outrow, int slot, const uint32_t 
 		o[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
 }
 
+// The same store for a whole wave, transposed through LDS.  Every lane holds one slot's outputs (64 / 128 contiguous
+// bytes) for a row of its own; stored lane by lane, each instruction touches 64 cache lines with 16 bytes each --
+// measured (profiles/ubench/hbm_mix): 1.1 TB/s for such a kernel alone instead of 4.4-4.7, 2.76x its bytes at the
+// memory side, and a coalesced reader running beside it drops to 0.47 TB/s instead of 1.1.  Through the tile each store
+// instruction writes 16 rows x 64 (8 rows x 128) contiguous bytes.  ALL 64 lanes of the single-wave workgroup call this
+// together; dst == nullptr: nothing to store for this lane.  Rows are padded by 16 bytes: the b128 writes are
+// conflict-free, the reads 2-way.  No barrier: the LDS executes one wave's instructions in order, and a workgroup
+// barrier's fence would wait for the slot loads in flight (that alone cost 25 % of these passes).
+template <bool WHB>
+struct K3Tile {
+	static constexpr int kBytes = WHB ? 128 : 64, kStride = kBytes + 16, kSize = 64 * kStride + 64 * 8;
+};
+template <bool WHB>
+__device__ __forceinline__ void k3_store_t(uint8_t *tile, void *dst, const uint32_t (&ow)[WHB ? 32 : 16])
+{
+	constexpr int RS = K3Tile<WHB>::kStride, PIECES = K3Tile<WHB>::kBytes / 16, RPI = 64 / PIECES;
+	const int ln = threadIdx.x & 63;
+	const unsigned long long valid = __ballot(dst != nullptr);
+	if (valid == 0ull)
+		return;
+	uint4 *mine = reinterpret_cast<uint4 *>(tile + ln * RS);
+#pragma unroll
+	for (int i = 0; i < PIECES; i++)
+		mine[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+	reinterpret_cast<unsigned long long *>(tile + 64 * RS)[ln] = (unsigned long long)(uintptr_t)dst;
+	__builtin_amdgcn_wave_barrier();
+	const int piece = ln % PIECES, rsub = ln / PIECES;
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(1))) u32x4 global_u32x4;  // (a global, not a flat store)
+#pragma unroll
+	for (int k = 0; k < PIECES; k++) {
+		const int r = k * RPI + rsub;
+		const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + r * RS + 16 * piece);
+		const unsigned long long a = reinterpret_cast<const unsigned long long *>(tile + 64 * RS)[r];
+		if (a)
+			*(global_u32x4 *)(uintptr_t)(a + 16 * piece) = v;
+	}
+	__builtin_amdgcn_wave_barrier();
+}
+
 struct SegWin {
 	int og, n, nch, slot0;
 };
@@ -502,13 +542,16 @@ __device__ __forceinline__ void seg_advance(SegCursor &p, const WinTables &T, in
 }
 
 template <bool WHB, bool REPAIR>
-__device__ __forceinline__ int seg_run(Biquad &f, const BiquadCoef &cf, const void *in, void *out, uint32_t prev0,
-				       const WinTables &T, int c, int M, int count, int j, int i, int nslots, int min_slots,
-				       bool &converged)
+__device__ __forceinline__ int seg_run(uint8_t *tile, bool run, Biquad &f, const BiquadCoef &cf, const void *in, void *out,
+				       uint32_t prev0, const WinTables &T, int c, int M, int count, int j, int i, int nslots,
+				       int min_slots, bool &converged)
 {
+	// Called by all 64 lanes together (the outputs leave through the wave's LDS tile, k3_store_t); run == false: this
+	// lane has no segment and only helps to store.
 	double2 *ckrow = T.ckpt + (size_t)c * T.slots;
 	int done = 0, nsamples = 0;
 	converged = false;
+	bool alive = run && nslots > 0;
 	// three slot buffers in rotation: slot k is filtered while slots k+1 and k+2 are in flight (a lane streams its
 	// own row: what bounds these passes is the latency of the scattered 16-byte loads, not their bandwidth)
 	K3Chunk<WHB> A, B, C;
@@ -516,7 +559,9 @@ __device__ __forceinline__ int seg_run(Biquad &f, const BiquadCoef &cf, const vo
 	SegCursor pp, pl;  // processing / loading position
 	pp.j = j;
 	pp.i = i;
-	pp.w = seg_win(T, c, j, M);
+	pp.w = SegWin{ 0, 0, 1, 0 };
+	if (alive)
+		pp.w = seg_win(T, c, j, M);
 	pl = pp;
 	int loaded = 0;
 	auto fetch = [&](K3Chunk<WHB> &buf, double2 &ck) {
@@ -529,30 +574,38 @@ __device__ __forceinline__ int seg_run(Biquad &f, const BiquadCoef &cf, const vo
 				seg_advance(pl, T, c, M, count);
 		}
 	};
-	fetch(A, ckA);
-	fetch(B, ckB);
-	// one slot: `cur` is loaded; the buffer freed by the previous slot receives slot k+2; false = stop
-	auto one = [&](const K3Chunk<WHB> &cur, const double2 &ckcur, K3Chunk<WHB> &spare, double2 &ckspare) -> bool {
-		fetch(spare, ckspare);
-		uint32_t ow[WHB ? 32 : 16];
-		const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
-		k3_filter<WHB>(f, cf, cur, nv, ow);
-		k3_store<WHB>(out, pp.w.slot0 + pp.i, ow);
-		nsamples += nv;
-		done++;
-		if (!REPAIR) {
-			ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
-		} else if (same_bits(f.yn, ckcur.x) && same_bits(f.yn1, ckcur.y) && nsamples >= 2 && done >= min_slots) {
-			converged = true;
-			return false;
-		}
-		if (done >= nslots)
-			return false;
-		seg_advance(pp, T, c, M, count);
-		return true;
-	};
-	while (one(A, ckA, C, ckC) && one(B, ckB, A, ckA) && one(C, ckC, B, ckB)) {
+	if (alive) {
+		fetch(A, ckA);
+		fetch(B, ckB);
 	}
+	// one slot: `cur` is loaded; the buffer freed by the previous slot receives slot k+2; false = no lane has more
+	auto one = [&](const K3Chunk<WHB> &cur, const double2 &ckcur, K3Chunk<WHB> &spare, double2 &ckspare) -> bool {
+		uint32_t ow[WHB ? 32 : 16];
+		void *dst = nullptr;
+		if (alive) {
+			fetch(spare, ckspare);
+			const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
+			k3_filter<WHB>(f, cf, cur, nv, ow);
+			dst = static_cast<uint32_t *>(out) + (size_t)(pp.w.slot0 + pp.i) * (WHB ? 32 : 16);
+			nsamples += nv;
+			done++;
+			if (!REPAIR) {
+				ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
+			} else if (same_bits(f.yn, ckcur.x) && same_bits(f.yn1, ckcur.y) && nsamples >= 2 && done >= min_slots) {
+				converged = true;
+				alive = false;
+			}
+			if (done >= nslots)
+				alive = false;
+			if (alive)
+				seg_advance(pp, T, c, M, count);
+		}
+		k3_store_t<WHB>(tile, dst, ow);
+		return __ballot(alive) != 0ull;
+	};
+	if (__ballot(alive) != 0ull)
+		while (one(A, ckA, C, ckC) && one(B, ckB, A, ckA) && one(C, ckC, B, ckB)) {
+		}
 	return done;
 }
 
@@ -572,11 +625,12 @@ __device__ __forceinline__ BiquadEnd end_of(const Biquad &f)
 // K3a (repair = 0), K3b (repair = 1) and K3b' (repair = 2: segments whose predecessor's repair run did not
 // converge are run once more, from THAT run's end state); whb: 0 = TFA_2-family chains, 1 = WHB chains
 template <bool WHB>
-__device__ __forceinline__ void seg_task(uint2 it, int repair, int n_streams, int M, const uint32_t *__restrict__ dec,
-					 size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
-					 const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
+__device__ __forceinline__ void seg_task(uint8_t *tile, bool have, uint2 it, int repair, int n_streams, int M,
+					 const uint32_t *__restrict__ dec, size_t dec_stride, const int16_t *__restrict__ fmdev,
+					 size_t fmdev_stride, const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
 					 int32_t *__restrict__ dev32)
 {
+	// all 64 lanes come here together; have == false: no item for this lane (it = chain 0, segment 0: reads stay in bounds)
 	const int c = (int)it.x, k = (int)it.y;
 	const int a = c / n_streams, s = c - a * n_streams;
 	const ChainState &st = L.states[a][s];
@@ -590,17 +644,19 @@ __device__ __forceinline__ void seg_task(uint2 it, int repair, int n_streams, in
 	const size_t sk = (size_t)c * T.segcap + k;
 	bool conv;
 	Biquad f;
+	f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
 	if (!repair) {
 		if (k == 0)
 			f = st.iir;  // the chain's first segment starts from the true carried state
-		else
-			f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
-		(void)seg_run<WHB, false>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
-		T.segend1[sk] = end_of(f);
+		(void)seg_run<WHB, false>(tile, have, f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
+		if (have)
+			T.segend1[sk] = end_of(f);
 	} else if (repair == 1) {
-		if (k > 0) {
+		const bool run = have && k > 0;
+		if (run)
 			f = biquad_of(T.segend1[sk - 1]);
-			const int done = seg_run<WHB, true>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
+		const int done = seg_run<WHB, true>(tile, run, f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
+		if (run) {
 			T.segfix[sk] = done | (conv ? kSegConverged : 0);
 			if (!conv) {
 				T.segend2[sk] = end_of(f);
@@ -608,42 +664,51 @@ __device__ __forceinline__ void seg_task(uint2 it, int repair, int n_streams, in
 			}
 		}
 	} else {
-		int fx2 = 0;
-		if (k > 1 && !(T.segfix[sk - 1] & kSegConverged)) {
-			// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
-			// the true one, its end state segend2[k-1] is where segment k really starts
+		// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
+		// the true one, its end state segend2[k-1] is where segment k really starts
+		const bool run = have && k > 1 && !(T.segfix[sk - 1] & kSegConverged);
+		int min_slots = 0;
+		if (run) {
 			f = biquad_of(T.segend2[sk - 1]);
-			const int done = seg_run<WHB, true>(f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots,
-							    T.segfix[sk] & ~kSegConverged, conv);
-			fx2 = done | (conv ? kSegConverged : 0) | kSegRan;
-			if (!conv)
-				T.segend3[sk] = end_of(f);
+			min_slots = T.segfix[sk] & ~kSegConverged;
 		}
-		T.segfix2[sk] = fx2;
+		const int done = seg_run<WHB, true>(tile, run, f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots,
+						    min_slots, conv);
+		if (have) {
+			int fx2 = 0;
+			if (run) {
+				fx2 = done | (conv ? kSegConverged : 0) | kSegRan;
+				if (!conv)
+					T.segend3[sk] = end_of(f);
+			}
+			T.segfix2[sk] = fx2;
+		}
 	}
 }
 
+template <bool WHB>
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							 int32_t *__restrict__ dev32, int lanes, int whb, int repair)
+							 int32_t *__restrict__ dev32, int lanes, int repair)
 {
-	if ((int)threadIdx.x >= lanes)
-		return;
+	constexpr int whb = WHB ? 1 : 0;
+	extern __shared__ __attribute__((aligned(16))) uint8_t k3_tile[];  // K3Tile<whb>::kSize bytes
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int q = 4 + 2 * whb;
 	const uint32_t count = T.queue[q].count;
 	uint32_t *head = repair == 0 ? &T.queue[q].head : (repair == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
+	const bool worker = (int)threadIdx.x < lanes;  // the other lanes only help to store (k3_store_t)
 	while (true) {
-		const uint32_t idx = atomicAdd(head, 1u);
-		if (idx >= count)
+		uint32_t idx = count;
+		if (worker)
+			idx = atomicAdd(head, 1u);
+		const bool have = idx < count;
+		if (__ballot(have) == 0ull)
 			break;
-		const uint2 it = T.items[(size_t)q * total + idx];
-		if (whb)
-			seg_task<true>(it, repair, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
-		else
-			seg_task<false>(it, repair, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+		const uint2 it = have ? T.items[(size_t)q * total + idx] : make_uint2(0u, 0u);
+		seg_task<WHB>(k3_tile, have, it, repair, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
 	}
 }
 
@@ -2581,13 +2646,13 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	if (has_whb) {
 		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
 		mark(9, P.kw);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 0);
+		hipLaunchKernelGGL(spec_biquad_kernel<true>, dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0);
 		mark(10, P.kw);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 1);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 1, 2);
+		hipLaunchKernelGGL(spec_biquad_kernel<true>, dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 1);
+		hipLaunchKernelGGL(spec_biquad_kernel<true>, dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 2);
 		mark(11, P.kw);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 2);
@@ -2642,8 +2707,8 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			mark(25, P.k2);
 		}
 		mark(1, P.k2);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 0);
+		hipLaunchKernelGGL(spec_biquad_kernel<false>, dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 0);
 		mark(2, P.k2);
 		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
 			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
@@ -2652,10 +2717,10 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 1);
-		hipLaunchKernelGGL(spec_biquad_kernel, dim3(seg_blocks), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0, 2);
+		hipLaunchKernelGGL(spec_biquad_kernel<false>, dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 1);
+		hipLaunchKernelGGL(spec_biquad_kernel<false>, dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
+				   n_blocks, L, T, ld16, dev32, lanes_win, 2);
 		mark(3, P.k2);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 1);
