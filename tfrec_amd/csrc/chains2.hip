@@ -417,18 +417,19 @@ __device__ __forceinline__ void k3_load(K3Chunk<WHB> &ch, const void *row, int g
 	}
 }
 
-// Filter `nvalid` samples of a chunk (groups of 8: unpredicated while the whole group is valid).
-template <bool WHB>
-__device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const K3Chunk<WHB> &ch, int nvalid,
-					  uint32_t (&ow)[WHB ? 32 : 16])
+// Filter `nvalid` samples of a chunk (groups of 8: unpredicated while the whole group is valid).  emit(grp, g): the
+// group's outputs, packed as they are stored (4 dwords of int16 pairs, WHB: 8 int32), zeros beyond nvalid.
+template <bool WHB, class Emit>
+__device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const K3Chunk<WHB> &ch, int nvalid, Emit emit)
 {
 	int pI = (int)(int16_t)(ch.prevw & 0xffff), pQ = (int)ch.prevw >> 16;
 	BiquadT bt = iirt_enter(f, cf);
 #pragma unroll
-	for (int i = 0; i < (WHB ? 32 : 16); i++)
-		ow[i] = 0;
-#pragma unroll
 	for (int grp = 0; grp < 4; grp++) {
+		uint32_t g[WHB ? 8 : 4];
+#pragma unroll
+		for (int i = 0; i < (WHB ? 8 : 4); i++)
+			g[i] = 0;
 		auto one = [&](int k) {
 			int y;
 			if (WHB) {
@@ -436,11 +437,11 @@ __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const
 				y = (int)iir_step_t(f, bt, cf, (double)fm_dev_nrzs(I, Q, pI, pQ));  // whb.cpp:651-652
 				pI = I;
 				pQ = Q;
-				ow[k] = (uint32_t)y;
+				g[k & 7] = (uint32_t)y;
 			} else {
 				const int x = (int)(int16_t)((ch.w[k >> 1] >> (16 * (k & 1))) & 0xffff);
 				y = (int)iir_step_t(f, bt, cf, (double)x);  // tfa2.cpp:362
-				ow[k >> 1] |= ((uint32_t)y & 0xffffu) << (16 * (k & 1));
+				g[(k & 7) >> 1] |= ((uint32_t)y & 0xffffu) << (16 * (k & 1));
 			}
 		};
 		__builtin_amdgcn_sched_barrier(0);  // bound the live range of the per-sample products to one group
@@ -454,7 +455,19 @@ __device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const
 				if (k < nvalid)
 					one(k);
 		}
+		emit(grp, g);
 	}
+}
+// ... into a register image of the slot (the serial repair of fix_biquad_kernel)
+template <bool WHB>
+__device__ __forceinline__ void k3_filter(Biquad &f, const BiquadCoef &cf, const K3Chunk<WHB> &ch, int nvalid,
+					  uint32_t (&ow)[WHB ? 32 : 16])
+{
+	k3_filter<WHB>(f, cf, ch, nvalid, [&](int grp, const uint32_t (&g)[WHB ? 8 : 4]) {
+#pragma unroll
+		for (int i = 0; i < (WHB ? 8 : 4); i++)
+			ow[(WHB ? 8 : 4) * grp + i] = g[i];
+	});
 }
 
 template <bool WHB>
@@ -479,17 +492,15 @@ struct K3Tile {
 	static constexpr int kBytes = WHB ? 128 : 64, kStride = kBytes + 16, kSize = 64 * kStride + 64 * 8;
 };
 template <bool WHB>
-__device__ __forceinline__ void k3_store_t(uint8_t *tile, void *dst, const uint32_t (&ow)[WHB ? 32 : 16])
+__device__ __forceinline__ uint8_t *k3_tile_row(uint8_t *tile) { return tile + (threadIdx.x & 63) * K3Tile<WHB>::kStride; }
+// (the filter has written this lane's row: k3_tile_row)
+template <bool WHB>
+__device__ __forceinline__ void k3_store_t(uint8_t *tile, void *dst)
 {
 	constexpr int RS = K3Tile<WHB>::kStride, PIECES = K3Tile<WHB>::kBytes / 16, RPI = 64 / PIECES;
 	const int ln = threadIdx.x & 63;
-	const unsigned long long valid = __ballot(dst != nullptr);
-	if (valid == 0ull)
+	if (__ballot(dst != nullptr) == 0ull)
 		return;
-	uint4 *mine = reinterpret_cast<uint4 *>(tile + ln * RS);
-#pragma unroll
-	for (int i = 0; i < PIECES; i++)
-		mine[i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
 	reinterpret_cast<unsigned long long *>(tile + 64 * RS)[ln] = (unsigned long long)(uintptr_t)dst;
 	__builtin_amdgcn_wave_barrier();
 	const int piece = ln % PIECES, rsub = ln / PIECES;
@@ -552,10 +563,12 @@ __device__ __forceinline__ int seg_run(uint8_t *tile, bool run, Biquad &f, const
 	int done = 0, nsamples = 0;
 	converged = false;
 	bool alive = run && nslots > 0;
-	// three slot buffers in rotation: slot k is filtered while slots k+1 and k+2 are in flight (a lane streams its
-	// own row: what bounds these passes is the latency of the scattered 16-byte loads, not their bandwidth)
-	K3Chunk<WHB> A, B, C;
-	double2 ckA = make_double2(0, 0), ckB = ckA, ckC = ckA;
+	// two slot buffers: slot k is filtered while slot k+1 is in flight, and slot k+2 is requested into k's buffer as
+	// soon as k is done.  (A third buffer -- two slots in flight throughout -- made the pass faster alone and the
+	// batch slower: 30-50 more registers per lane on a chip whose register file is what the concurrent kernels
+	// compete for)
+	K3Chunk<WHB> A, B;
+	double2 ckA = make_double2(0, 0), ckB = ckA;
 	SegCursor pp, pl;  // processing / loading position
 	pp.j = j;
 	pp.i = i;
@@ -578,14 +591,20 @@ __device__ __forceinline__ int seg_run(uint8_t *tile, bool run, Biquad &f, const
 		fetch(A, ckA);
 		fetch(B, ckB);
 	}
-	// one slot: `cur` is loaded; the buffer freed by the previous slot receives slot k+2; false = no lane has more
-	auto one = [&](const K3Chunk<WHB> &cur, const double2 &ckcur, K3Chunk<WHB> &spare, double2 &ckspare) -> bool {
-		uint32_t ow[WHB ? 32 : 16];
+	// one slot: `cur` is loaded and receives slot k+2 once it has been filtered; false = no lane has more
+	auto one = [&](K3Chunk<WHB> &cur, double2 &ckcur) -> bool {
 		void *dst = nullptr;
 		if (alive) {
-			fetch(spare, ckspare);
 			const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
-			k3_filter<WHB>(f, cf, cur, nv, ow);
+			uint4 *row = reinterpret_cast<uint4 *>(k3_tile_row<WHB>(tile));  // the transposed reads of the last slot were issued before
+			k3_filter<WHB>(f, cf, cur, nv, [&](int grp, const uint32_t (&g)[WHB ? 8 : 4]) {
+				if (WHB) {
+					row[2 * grp] = make_uint4(g[0], g[1], g[2], g[3]);
+					row[2 * grp + 1] = make_uint4(g[WHB ? 4 : 0], g[WHB ? 5 : 0], g[WHB ? 6 : 0], g[WHB ? 7 : 0]);
+				} else {
+					row[grp] = make_uint4(g[0], g[1], g[2], g[3]);
+				}
+			});
 			dst = static_cast<uint32_t *>(out) + (size_t)(pp.w.slot0 + pp.i) * (WHB ? 32 : 16);
 			nsamples += nv;
 			done++;
@@ -597,14 +616,16 @@ __device__ __forceinline__ int seg_run(uint8_t *tile, bool run, Biquad &f, const
 			}
 			if (done >= nslots)
 				alive = false;
-			if (alive)
+			if (alive) {
 				seg_advance(pp, T, c, M, count);
+				fetch(cur, ckcur);
+			}
 		}
-		k3_store_t<WHB>(tile, dst, ow);
+		k3_store_t<WHB>(tile, dst);
 		return __ballot(alive) != 0ull;
 	};
 	if (__ballot(alive) != 0ull)
-		while (one(A, ckA, C, ckC) && one(B, ckB, A, ckA) && one(C, ckC, B, ckB)) {
+		while (one(A, ckA) && one(B, ckB)) {
 		}
 	return done;
 }
@@ -1901,6 +1922,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	constexpr int kStep = 64;  // samples per iteration: one per lane
 	const int ln = threadIdx.x;
 	const int s = blockIdx.x;  // one wave per stream
+	uint8_t *const rdata_wave = rdata_lds;
 	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
 	const int count = T.count[c];
@@ -2253,11 +2275,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	__threadfence();  // the runs, results and start registers
 	__syncthreads();
 	for (int j = ln; j < count; j += 64)
-		whb_decode_window(s, j, n_streams, L, a, T, rdata_lds + 64 * ln);
+		whb_decode_window(s, j, n_streams, L, a, T, rdata_wave + 64 * ln);
 	__threadfence();
 	__syncthreads();
 	if (ln == 0)
-		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_lds);
+		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_wave);
 }
 
 
@@ -2667,8 +2689,10 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 				// front-end workgroups (25 KB each of the CU's 160 KB) the 17 KB it used to ask for did not fit at all, so it
 				// trickled onto the chip at the front end's pace.  TFREC_AMD_WHB_LDS raises it (caps the workgroups per CU).
 				static const int whb_lds = std::max(64 * 64, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
-				hipLaunchKernelGGL(whb_demod_kernel, dim3(n_streams), block, whb_lds, P.aux, dec, dec_stride, dev32, n_streams,
-						   n_blocks, sample_base, L, a, T, events, eb, flags);
+				const dim3 wgrid(n_streams), wblock(64);
+				const int wlds = whb_lds;
+				hipLaunchKernelGGL(whb_demod_kernel, wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams, n_blocks,
+						   sample_base, L, a, T, events, eb, flags);
 				mark(13, P.aux);
 				mark(14, P.aux);
 				mark(15, P.aux);
