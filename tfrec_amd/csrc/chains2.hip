@@ -552,84 +552,6 @@ __device__ __forceinline__ void seg_advance(SegCursor &p, const WinTables &T, in
 	}
 }
 
-template <bool WHB, bool REPAIR>
-__device__ __forceinline__ int seg_run(uint8_t *tile, bool run, Biquad &f, const BiquadCoef &cf, const void *in, void *out,
-				       uint32_t prev0, const WinTables &T, int c, int M, int count, int j, int i, int nslots,
-				       int min_slots, bool &converged)
-{
-	// Called by all 64 lanes together (the outputs leave through the wave's LDS tile, k3_store_t); run == false: this
-	// lane has no segment and only helps to store.
-	double2 *ckrow = T.ckpt + (size_t)c * T.slots;
-	int done = 0, nsamples = 0;
-	converged = false;
-	bool alive = run && nslots > 0;
-	// two slot buffers: slot k is filtered while slot k+1 is in flight, and slot k+2 is requested into k's buffer as
-	// soon as k is done.  (A third buffer -- two slots in flight throughout -- made the pass faster alone and the
-	// batch slower: 30-50 more registers per lane on a chip whose register file is what the concurrent kernels
-	// compete for)
-	K3Chunk<WHB> A, B;
-	double2 ckA = make_double2(0, 0), ckB = ckA;
-	SegCursor pp, pl;  // processing / loading position
-	pp.j = j;
-	pp.i = i;
-	pp.w = SegWin{ 0, 0, 1, 0 };
-	if (alive)
-		pp.w = seg_win(T, c, j, M);
-	pl = pp;
-	int loaded = 0;
-	auto fetch = [&](K3Chunk<WHB> &buf, double2 &ck) {
-		if (loaded < nslots) {
-			k3_load<WHB>(buf, in, pl.w.og + kChunk * pl.i, prev0);
-			if (REPAIR)
-				ck = ckrow[pl.w.slot0 + pl.i];
-			loaded++;
-			if (loaded < nslots)
-				seg_advance(pl, T, c, M, count);
-		}
-	};
-	if (alive) {
-		fetch(A, ckA);
-		fetch(B, ckB);
-	}
-	// one slot: `cur` is loaded and receives slot k+2 once it has been filtered; false = no lane has more
-	auto one = [&](K3Chunk<WHB> &cur, double2 &ckcur) -> bool {
-		void *dst = nullptr;
-		if (alive) {
-			const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
-			uint4 *row = reinterpret_cast<uint4 *>(k3_tile_row<WHB>(tile));  // the transposed reads of the last slot were issued before
-			k3_filter<WHB>(f, cf, cur, nv, [&](int grp, const uint32_t (&g)[WHB ? 8 : 4]) {
-				if (WHB) {
-					row[2 * grp] = make_uint4(g[0], g[1], g[2], g[3]);
-					row[2 * grp + 1] = make_uint4(g[WHB ? 4 : 0], g[WHB ? 5 : 0], g[WHB ? 6 : 0], g[WHB ? 7 : 0]);
-				} else {
-					row[grp] = make_uint4(g[0], g[1], g[2], g[3]);
-				}
-			});
-			dst = static_cast<uint32_t *>(out) + (size_t)(pp.w.slot0 + pp.i) * (WHB ? 32 : 16);
-			nsamples += nv;
-			done++;
-			if (!REPAIR) {
-				ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
-			} else if (same_bits(f.yn, ckcur.x) && same_bits(f.yn1, ckcur.y) && nsamples >= 2 && done >= min_slots) {
-				converged = true;
-				alive = false;
-			}
-			if (done >= nslots)
-				alive = false;
-			if (alive) {
-				seg_advance(pp, T, c, M, count);
-				fetch(cur, ckcur);
-			}
-		}
-		k3_store_t<WHB>(tile, dst);
-		return __ballot(alive) != 0ull;
-	};
-	if (__ballot(alive) != 0ull)
-		while (one(A, ckA) && one(B, ckB)) {
-		}
-	return done;
-}
-
 __device__ __forceinline__ Biquad biquad_of(const BiquadEnd &e)
 {
 	Biquad f;
@@ -643,93 +565,176 @@ __device__ __forceinline__ BiquadEnd end_of(const Biquad &f)
 	return e;
 }
 
-// K3a (repair = 0), K3b (repair = 1) and K3b' (repair = 2: segments whose predecessor's repair run did not
-// converge are run once more, from THAT run's end state); whb: 0 = TFA_2-family chains, 1 = WHB chains
-template <bool WHB>
-__device__ __forceinline__ void seg_task(uint8_t *tile, bool have, uint2 it, int repair, int n_streams, int M,
-					 const uint32_t *__restrict__ dec, size_t dec_stride, const int16_t *__restrict__ fmdev,
-					 size_t fmdev_stride, const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
-					 int32_t *__restrict__ dev32)
-{
-	// all 64 lanes come here together; have == false: no item for this lane (it = chain 0, segment 0: reads stay in bounds)
-	const int c = (int)it.x, k = (int)it.y;
-	const int a = c / n_streams, s = c - a * n_streams;
-	const ChainState &st = L.states[a][s];
-	const uint2 start = T.segstart[(size_t)c * T.segcap + k];
-	const int j = (int)start.x, i = (int)start.y;
-	const int left = T.vtotal[c] - k * kSegSlots;
-	const int nslots = left < kSegSlots ? left : kSegSlots;
-	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
-	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
-	const uint32_t prev0 = T.prevdec[s];  // not st.prev_i/q: stage B of the previous submit may still be running
-	const size_t sk = (size_t)c * T.segcap + k;
-	bool conv;
-	Biquad f;
-	f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
-	if (!repair) {
-		if (k == 0)
-			f = st.iir;  // the chain's first segment starts from the true carried state
-		(void)seg_run<WHB, false>(tile, have, f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
-		if (have)
-			T.segend1[sk] = end_of(f);
-	} else if (repair == 1) {
-		const bool run = have && k > 0;
-		if (run)
-			f = biquad_of(T.segend1[sk - 1]);
-		const int done = seg_run<WHB, true>(tile, run, f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots, 0, conv);
-		if (run) {
-			T.segfix[sk] = done | (conv ? kSegConverged : 0);
-			if (!conv) {
-				T.segend2[sk] = end_of(f);
-				atomicAdd(&T.stats[1], 1ull);
-			}
-		}
-	} else {
-		// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
-		// the true one, its end state segend2[k-1] is where segment k really starts
-		const bool run = have && k > 1 && !(T.segfix[sk - 1] & kSegConverged);
-		int min_slots = 0;
-		if (run) {
-			f = biquad_of(T.segend2[sk - 1]);
-			min_slots = T.segfix[sk] & ~kSegConverged;
-		}
-		const int done = seg_run<WHB, true>(tile, run, f, L.params[a].iir, in, out, prev0, T, c, M, T.count[c], j, i, nslots,
-						    min_slots, conv);
-		if (have) {
-			int fx2 = 0;
-			if (run) {
-				fx2 = done | (conv ? kSegConverged : 0) | kSegRan;
-				if (!conv)
-					T.segend3[sk] = end_of(f);
-			}
-			T.segfix2[sk] = fx2;
-		}
-	}
-}
-
-template <bool WHB>
+// K3a (MODE 0), K3b (MODE 1) and K3b' (MODE 2: segments whose predecessor's repair run did not converge are run once
+// more, from THAT run's end state); WHB: the WHB chains (int32 outputs from the decimated samples) or the TFA_2-family
+// chains (int16 outputs from the fm_dev array).
+//
+// A flat loop: per iteration every busy lane filters ONE slot of its segment, and all 64 lanes store the wave's slots
+// together (k3_store_t).  A lane that finishes its segment takes the next one from the work queue by itself -- the lanes
+// of a wave do not wait for each other's segments.  (They did: a repair run takes ~20 slots for most segments but the
+// whole segment, 116 slots, for the 1 % whose two trajectories never become bit-identical; with one such lane in
+// every second wave the repair passes took as long as the speculative pass.)  Taking a segment costs a few dependent
+// table reads during which the wave stalls, so idle lanes wait until a quarter of the wave is idle (or nothing runs).
+// Two slot buffers per lane: slot k (A) is filtered while slot k+1 (B) is in flight; then B moves to A and slot k+2 is
+// requested.  (A third buffer -- two slots in flight throughout -- made the pass faster alone and the batch slower: 30-50
+// more registers per lane)
+template <bool WHB, int MODE>
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							 int32_t *__restrict__ dev32, int lanes, int repair)
+							 int32_t *__restrict__ dev32, int lanes)
 {
-	constexpr int whb = WHB ? 1 : 0;
-	extern __shared__ __attribute__((aligned(16))) uint8_t k3_tile[];  // K3Tile<whb>::kSize bytes
+	constexpr bool REPAIR = MODE != 0;
+	extern __shared__ __attribute__((aligned(16))) uint8_t k3_tile[];  // K3Tile<WHB>::kSize bytes
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
-	const int q = 4 + 2 * whb;
-	const uint32_t count = T.queue[q].count;
-	uint32_t *head = repair == 0 ? &T.queue[q].head : (repair == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
-	const bool worker = (int)threadIdx.x < lanes;  // the other lanes only help to store (k3_store_t)
+	constexpr int q = 4 + 2 * (WHB ? 1 : 0);
+	const uint32_t qcount = T.queue[q].count;
+	uint32_t *head = MODE == 0 ? &T.queue[q].head : (MODE == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
+	const bool worker = (int)threadIdx.x < lanes;  // the other lanes only help to store
+	bool busy = false, dry = !worker;
+	// the lane's segment
+	int c = 0, count = 0, nslots = 0, min_slots = 0, done = 0, nsamples = 0, loaded = 0;
+	size_t sk = 0;
+	const void *in = nullptr;
+	void *out = nullptr;
+	double2 *ckrow = nullptr;
+	uint32_t prev0 = 0;
+	BiquadCoef cf = {};
+	Biquad f;
+	f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
+	K3Chunk<WHB> A, B;
+	double2 ckA = make_double2(0, 0), ckB = ckA;
+	SegCursor pp, pl;  // processing / loading position
+	pp.j = pp.i = 0;
+	pp.w = SegWin{ 0, 0, 1, 0 };
+	pl = pp;
+	auto fetch = [&](K3Chunk<WHB> &buf, double2 &ck) {
+		if (loaded < nslots) {
+			k3_load<WHB>(buf, in, pl.w.og + kChunk * pl.i, prev0);
+			if (REPAIR)
+				ck = ckrow[pl.w.slot0 + pl.i];
+			loaded++;
+			if (loaded < nslots)
+				seg_advance(pl, T, c, M, count);
+		}
+	};
 	while (true) {
-		uint32_t idx = count;
-		if (worker)
-			idx = atomicAdd(head, 1u);
-		const bool have = idx < count;
-		if (__ballot(have) == 0ull)
-			break;
-		const uint2 it = have ? T.items[(size_t)q * total + idx] : make_uint2(0u, 0u);
-		seg_task<WHB>(k3_tile, have, it, repair, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+		// ---- take segments
+		const unsigned long long idle = __ballot(!busy && !dry), running = __ballot(busy);
+		if (idle != 0ull && (running == 0ull || __builtin_popcountll(idle) >= 16)) {
+			while (!busy && !dry) {  // (a segment with nothing to run is finished on the spot)
+				const uint32_t idx = atomicAdd(head, 1u);
+				if (idx >= qcount) {
+					dry = true;
+					break;
+				}
+				const uint2 it = T.items[(size_t)q * total + idx];
+				c = (int)it.x;
+				const int k = (int)it.y;
+				const int a = c / n_streams, s = c - a * n_streams;
+				sk = (size_t)c * T.segcap + k;
+				bool run = true;
+				f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
+				min_slots = 0;
+				if (MODE == 0) {
+					if (k == 0)
+						f = L.states[a][s].iir;  // the chain's first segment starts from the true carried state
+				} else if (MODE == 1) {
+					run = k > 0;
+					if (run)
+						f = biquad_of(T.segend1[sk - 1]);
+				} else {
+					// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
+					// the true one, its end state segend2[k-1] is where segment k really starts
+					run = k > 1 && !(T.segfix[sk - 1] & kSegConverged);
+					if (run) {
+						f = biquad_of(T.segend2[sk - 1]);
+						min_slots = T.segfix[sk] & ~kSegConverged;
+					} else {
+						T.segfix2[sk] = 0;
+					}
+				}
+				if (!run)
+					continue;
+				const int left = T.vtotal[c] - k * kSegSlots;
+				nslots = left < kSegSlots ? left : kSegSlots;
+				if (nslots <= 0) {  // (cannot happen: the queue holds existing segments)
+					if (MODE == 0)
+						T.segend1[sk] = end_of(f);
+					else if (MODE == 1)
+						T.segfix[sk] = 0;
+					else
+						T.segfix2[sk] = kSegRan;
+					continue;
+				}
+				const uint2 start = T.segstart[sk];
+				count = T.count[c];
+				cf = L.params[a].iir;
+				in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
+				out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
+				ckrow = T.ckpt + (size_t)c * T.slots;
+				prev0 = T.prevdec[s];  // not the chain state's prev_i/q: stage B of the previous submit may still be running
+				pp.j = (int)start.x;
+				pp.i = (int)start.y;
+				pp.w = seg_win(T, c, pp.j, M);
+				pl = pp;
+				done = nsamples = loaded = 0;
+				fetch(A, ckA);
+				fetch(B, ckB);
+				busy = true;
+			}
+		}
+		if (__ballot(busy) == 0ull) {
+			if (__ballot(!dry) == 0ull)
+				break;
+			continue;
+		}
+		// ---- one slot
+		void *dst = nullptr;
+		if (busy) {
+			const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
+			uint4 *row = reinterpret_cast<uint4 *>(k3_tile_row<WHB>(k3_tile));  // (the transposed reads of the last slot were issued before)
+			k3_filter<WHB>(f, cf, A, nv, [&](int grp, const uint32_t (&g)[WHB ? 8 : 4]) {
+				if (WHB) {
+					row[2 * grp] = make_uint4(g[0], g[1], g[2], g[3]);
+					row[2 * grp + 1] = make_uint4(g[WHB ? 4 : 0], g[WHB ? 5 : 0], g[WHB ? 6 : 0], g[WHB ? 7 : 0]);
+				} else {
+					row[grp] = make_uint4(g[0], g[1], g[2], g[3]);
+				}
+			});
+			dst = static_cast<uint32_t *>(out) + (size_t)(pp.w.slot0 + pp.i) * (WHB ? 32 : 16);
+			nsamples += nv;
+			done++;
+			bool conv = false;
+			if (!REPAIR)
+				ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
+			else  // the state equals the speculative checkpoint bit for bit (the two last inputs are then shared too): from
+			      // here on the stored trajectory is the continuation of this run
+				conv = same_bits(f.yn, ckA.x) && same_bits(f.yn1, ckA.y) && nsamples >= 2 && done >= min_slots;
+			if (conv || done >= nslots) {
+				busy = false;
+				if (MODE == 0) {
+					T.segend1[sk] = end_of(f);
+				} else if (MODE == 1) {
+					T.segfix[sk] = done | (conv ? kSegConverged : 0);
+					if (!conv) {
+						T.segend2[sk] = end_of(f);
+						atomicAdd(&T.stats[1], 1ull);
+					}
+				} else {
+					T.segfix2[sk] = done | (conv ? kSegConverged : 0) | kSegRan;
+					if (!conv)
+						T.segend3[sk] = end_of(f);
+				}
+			} else {
+				seg_advance(pp, T, c, M, count);
+				A = B;
+				ckA = ckB;
+				fetch(B, ckB);
+			}
+		}
+		k3_store_t<WHB>(k3_tile, dst);
 	}
 }
 
@@ -2668,13 +2673,13 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	if (has_whb) {
 		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
 		mark(9, P.kw);
-		hipLaunchKernelGGL(spec_biquad_kernel<true>, dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0);
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(10, P.kw);
-		hipLaunchKernelGGL(spec_biquad_kernel<true>, dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 1);
-		hipLaunchKernelGGL(spec_biquad_kernel<true>, dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 2);
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(11, P.kw);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 2);
@@ -2731,8 +2736,8 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			mark(25, P.k2);
 		}
 		mark(1, P.k2);
-		hipLaunchKernelGGL(spec_biquad_kernel<false>, dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 0);
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(2, P.k2);
 		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
 			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
@@ -2741,10 +2746,10 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}
-		hipLaunchKernelGGL(spec_biquad_kernel<false>, dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 1);
-		hipLaunchKernelGGL(spec_biquad_kernel<false>, dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams,
-				   n_blocks, L, T, ld16, dev32, lanes_win, 2);
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 1>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(3, P.k2);
 		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
 				   L, T, ld16, dev32, lanes_chain, 1);
