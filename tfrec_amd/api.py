@@ -216,7 +216,7 @@ class Receiver:
         _check(self.L, self.L.tfrec_amd_sync(self.h))
 
     def drain(self, allow_overflow: bool = False) -> np.ndarray:
-        out = np.zeros(self.max_events, dtype=EVENT_DTYPE)
+        out = np.empty(self.max_events, dtype=EVENT_DTYPE)
         n = C.c_int(0)
         rc = self.L.tfrec_amd_drain_events(self.h, out.ctypes.data, self.max_events, C.byref(n))
         _check(self.L, rc, ok=(E_OK, E_OVERFLOW) if allow_overflow else (E_OK,))

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -106,8 +107,16 @@ struct tfrec_amd_ctx {
 	tfrec_amd_event *d_events[kSets] = {};
 	EventBuf *d_eb[kSets] = {};
 	EventBuf *d_eb_fresh = nullptr;       // { 0, max_events, 0 }: copied over a set's EventBuf when a submit starts
-	tfrec_amd_event *h_events = nullptr;  // pinned staging for the drain
-	EventBuf *h_eb = nullptr;
+	// Pinned staging for the drain, one per set: the device-to-host copies of a submit's event buffer are queued on cp
+	// when the submit is made (behind its three end-of-chain events), so they are done when the host comes to drain it.
+	// The number of events is not known then: `copy_guess` of them are copied ahead (twice the last submit's count), the
+	// drain fetches the rest if there are more.
+	tfrec_amd_event *h_events[kSets] = {};
+	EventBuf *h_eb[kSets] = {};
+	hipEvent_t copied[kSets] = {};
+	uint32_t copied_n[kSets] = {};
+	uint32_t copy_guess = 4096;
+	std::vector<uint32_t> sort_idx, sort_start;
 	hipEvent_t done[kSets][3] = {};  // end of the submit that owns the set, on the cs / aux / t1 stream
 	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..TFREC_AMD_FIFO_DEPTH)
 	int last_drained = -1;
@@ -132,6 +141,9 @@ struct tfrec_amd_ctx {
 	// state, the FIFO's bookkeeping), so the context cannot continue exactly.  Every later submit / drain returns
 	// TFREC_AMD_E_STATE; destroy and recreate.
 	bool poisoned = false;
+	// TFREC_AMD_HOST_PROF=1: host-side time of the submit / drain calls, printed when the context is destroyed
+	double hp_submit = 0, hp_wait = 0, hp_copy = 0, hp_sort = 0;
+	long hp_n = 0;
 };
 
 namespace {
@@ -238,6 +250,10 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 {
 	if (!c)
 		return TFREC_AMD_OK;
+	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_n)
+		fprintf(stderr, "tfrec_amd host time per batch: submit %.0f us, drain: wait %.0f + copy %.0f + sort %.0f us (%ld batches)\n",
+			1e6 * c->hp_submit / c->hp_n, 1e6 * c->hp_wait / c->hp_n, 1e6 * c->hp_copy / c->hp_n, 1e6 * c->hp_sort / c->hp_n,
+			c->hp_n);
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipDeviceSynchronize();
 	for (int a = 0; a < kNSlots; a++)
@@ -293,10 +309,14 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 				(void)hipEventDestroy(e);
 	}
 	(void)hipFree(c->d_eb_fresh);
-	if (c->h_events)
-		(void)hipHostFree(c->h_events);
-	if (c->h_eb)
-		(void)hipHostFree(c->h_eb);
+	for (int k = 0; k < kSets; k++) {
+		if (c->h_events[k])
+			(void)hipHostFree(c->h_events[k]);
+		if (c->h_eb[k])
+			(void)hipHostFree(c->h_eb[k]);
+		if (c->copied[k])
+			(void)hipEventDestroy(c->copied[k]);
+	}
 	for (auto &p : c->d_stage)
 		(void)hipFree(p);
 	if (c->aux)
@@ -523,10 +543,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	}
 	ALLOC(c->d_eb_fresh, sizeof(EventBuf));
 #undef ALLOC
-	if (rc == TFREC_AMD_OK &&
-	    (hipHostMalloc((void **)&c->h_events, (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
-	     hipHostMalloc((void **)&c->h_eb, sizeof(EventBuf), hipHostMallocDefault) != hipSuccess))
-		rc = TFREC_AMD_E_NOMEM;
+	for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++)
+		if (hipHostMalloc((void **)&c->h_events[k], (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
+		    hipHostMalloc((void **)&c->h_eb[k], sizeof(EventBuf) + 16, hipHostMallocDefault) != hipSuccess ||  // + the window tables' overflow flag
+		    hipEventCreateWithFlags(&c->copied[k], hipEventDisableTiming) != hipSuccess)
+			rc = TFREC_AMD_E_NOMEM;
 	// Every pipeline stream except the biquad stages runs at high priority.  With the front end at low priority
 	// ("fill what the latency-bound chains leave free") its kernel stretched from 3 to 11 ms beside the chains and,
 	// with three submits in flight, became the longest stage of all: 13.4 ms per batch instead of 11.7.
@@ -697,6 +718,17 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
 				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
 	}
+	// the drain's copies, queued now
+	for (auto &e : c->done[set])
+		HIPCHK(hipStreamWaitEvent(c->cp, e, 0));
+	HIPCHK(hipMemcpyAsync(c->h_eb[set], c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->cp));
+	c->copied_n[set] = std::min<uint32_t>(c->copy_guess, (uint32_t)c->cfg.max_events);
+	HIPCHK(hipMemcpyAsync(c->h_events[set], c->d_events[set], (size_t)c->copied_n[set] * sizeof(tfrec_amd_event),
+			      hipMemcpyDeviceToHost, c->cp));
+	memset(c->h_eb[set] + 1, 0, 4);
+	if (c->win[set].overflow)
+		HIPCHK(hipMemcpyAsync(c->h_eb[set] + 1, c->win[set].overflow, 4, hipMemcpyDeviceToHost, c->cp));
+	HIPCHK(hipEventRecord(c->copied[set], c->cp));
 	if (timing)
 		c->timed = true;
 	c->inflight++;
@@ -710,7 +742,11 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 
 int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int n_blocks, void *hip_stream)
 {
-	return submit_common(c, d_iq, stride, n_blocks, hip_stream, false);
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = submit_common(c, d_iq, stride, n_blocks, hip_stream, false);
+	if (c)
+		c->hp_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return rc;
 }
 
 int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks)
@@ -774,11 +810,8 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 	if (c->inflight == 0)
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (auto &e : c->done[c->head])  // the oldest submit not yet drained
-		HIPCHK(hipEventSynchronize(e));
-	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[c->head], sizeof(EventBuf), hipMemcpyDeviceToHost, c->cp));
-	HIPCHK(hipStreamSynchronize(c->cp));
-	const EventBuf eb = *c->h_eb;
+	HIPCHK(hipEventSynchronize(c->copied[c->head]));  // the oldest submit not yet drained
+	const EventBuf eb = *c->h_eb[c->head];
 	*n = (int)std::min(eb.count, eb.capacity);
 	return eb.count > eb.capacity ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
 }
@@ -796,36 +829,33 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
 	const int set = c->head;  // the oldest submit not yet drained; a younger one may still be running
-	for (auto &e : c->done[set])
-		HIPCHK(hipEventSynchronize(e));
-	HIPCHK(hipMemcpyAsync(c->h_eb, c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, c->cp));
-	HIPCHK(hipStreamSynchronize(c->cp));
-	const EventBuf eb = *c->h_eb;
+	const auto hp0 = std::chrono::steady_clock::now();
+	HIPCHK(hipEventSynchronize(c->copied[set]));  // the chains' ends and the copies queued by the submit
+	const auto hp1 = std::chrono::steady_clock::now();
+	const EventBuf eb = *c->h_eb[set];
 	const uint32_t have = std::min(eb.count, eb.capacity);
 	bool overflow = eb.count > eb.capacity;
-	if (have) {
-		HIPCHK(hipMemcpyAsync(c->h_events, c->d_events[set], (size_t)have * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost,
-				      c->cp));
-		HIPCHK(hipStreamSynchronize(c->cp));
-	}
+	tfrec_amd_event *tmp = c->h_events[set];
+	if (have > c->copied_n[set])  // more events than the submit guessed (not on cp: the copies of younger submits wait there)
+		HIPCHK(hipMemcpy(tmp + c->copied_n[set], c->d_events[set] + c->copied_n[set],
+				 (size_t)(have - c->copied_n[set]) * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost));
+	c->copy_guess = std::max<uint32_t>(4096u, 2 * have);
 	c->head = (c->head + 1) % kSets;
 	c->inflight--;
 	c->last_drained = set;
 	account_fm_log(&c->fm, eb);
-	if (c->win[set].overflow) {
+	{
 		int32_t wov = 0;
-		HIPCHK(hipMemcpyAsync(c->h_eb, c->win[set].overflow, 4, hipMemcpyDeviceToHost, c->cp));
-		HIPCHK(hipStreamSynchronize(c->cp));
-		memcpy(&wov, c->h_eb, 4);
+		memcpy(&wov, c->h_eb[set] + 1, 4);
 		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
 			snprintf(g_err, sizeof(g_err), "window table overflow");
 			return TFREC_AMD_E_STATE;
 		}
 	}
-	tfrec_amd_event *tmp = c->h_events;
-	std::sort(tmp, tmp + have, [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
-		if (a.stream != b.stream)
-			return a.stream < b.stream;
+	const auto hp2 = std::chrono::steady_clock::now();
+	// Order: (stream, slot, seq, BITS chunks before their flush, end_sample, offset).  The events of a stream are few:
+	// bucket by stream (counting sort on indices), then order each bucket.
+	auto before = [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
 		if (a.slot != b.slot)
 			return a.slot < b.slot;
 		if (a.seq != b.seq)
@@ -837,15 +867,36 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 		if (a.end_sample != b.end_sample)
 			return a.end_sample < b.end_sample;
 		return a.offset < b.offset;
-	});
+	};
+	const uint32_t ns = (uint32_t)c->cfg.n_streams;
+	std::vector<uint32_t> &idx = c->sort_idx, &start = c->sort_start;
+	idx.resize(have);
+	start.assign(ns + 1, 0u);
+	for (uint32_t i = 0; i < have; i++)
+		start[std::min(tmp[i].stream, ns - 1) + 1]++;
+	for (uint32_t s = 0; s < ns; s++)
+		start[s + 1] += start[s];
+	{
+		std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+		for (uint32_t i = 0; i < have; i++)
+			idx[fill[std::min(tmp[i].stream, ns - 1)]++] = i;
+	}
+	for (uint32_t s = 0; s < ns; s++)
+		std::sort(idx.begin() + start[s], idx.begin() + start[s + 1],
+			  [&](uint32_t x, uint32_t y) { return before(tmp[x], tmp[y]); });
 	uint32_t ncopy = have;
 	if (ncopy > (uint32_t)cap) {
 		ncopy = (uint32_t)cap;
 		overflow = true;
 	}
-	if (ncopy)
-		memcpy(out, tmp, (size_t)ncopy * sizeof(tfrec_amd_event));
+	for (uint32_t i = 0; i < ncopy; i++)
+		out[i] = tmp[idx[i]];
 	*n_out = (int)ncopy;
+	const auto hp3 = std::chrono::steady_clock::now();
+	c->hp_wait += std::chrono::duration<double>(hp1 - hp0).count();
+	c->hp_copy += std::chrono::duration<double>(hp2 - hp1).count();
+	c->hp_sort += std::chrono::duration<double>(hp3 - hp2).count();
+	c->hp_n++;
 	return overflow ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
 }
 
