@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--h2d-steps", type=int, default=4, help="batches of the PCIe-inclusive leg (0 = skip; N=1 only)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short secondary measurements of BASELINE configs[1] and configs[4] (N=1 only)")
-    ap.add_argument("--depth", type=int, default=3, help="batches kept in the submit/drain FIFO (1..3)")
+    ap.add_argument("--depth", type=int, default=4, help="batches kept in the submit/drain FIFO (1..4)")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
                          "(secondary measurement; the default line stays config 2)")
@@ -305,7 +305,7 @@ def main():
             h2d = dict(error=str(e)[:200])
 
     # ---- secondary, short measurements of the other single-GPU configurations of BASELINE.json (never `value`): same
-    # method (input resident in HBM, FIFO of depth 3, parity gate on fresh state against the oracle)
+    # method (input resident in HBM, FIFO of depth 4, parity gate on fresh state against the oracle)
     extra = {}
     if world == 1 and not a.no_extra_configs and not a.input_10x and (n_streams, n_blocks, a.types) == (1024, 48, 0x2F):
         from oracle import oracle as O

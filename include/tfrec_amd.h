@@ -33,7 +33,9 @@ extern "C" {
 #endif
 
 #define TFREC_AMD_BLOCK_BYTES 65536 /* RLS, engine.cpp:68 */
-#define TFREC_AMD_FIFO_DEPTH 3  /* submits that may wait to be drained (tfrec_amd_drain_events) */
+#ifndef TFREC_AMD_FIFO_DEPTH
+#define TFREC_AMD_FIFO_DEPTH 4  /* submits that may wait to be drained (tfrec_amd_drain_events) */
+#endif
 #define TFREC_AMD_BLOCK_BYTES_10X 655360 /* one block of a 15.36 MS/s stream (TFREC_AMD_F_INPUT_10X) */
 #define TFREC_AMD_BLOCK_DEC 8192    /* decimated IQ pairs per block (4:1, dsp_stuff.cpp:243-264) */
 #define TFREC_AMD_NSLOTS 5
@@ -155,10 +157,12 @@ int tfrec_amd_sync(tfrec_amd_ctx *ctx);
  * (stream, slot, seq).  *n_out = number written (0 if nothing was submitted).  Returns TFREC_AMD_E_OVERFLOW if the
  * device buffer or cap was too small (the events that fit are still returned; the others are lost -- the decoder state and
  * the flush ordinals `seq` move on, so a gap in seq shows where).
- * Submits and drains form a FIFO of depth TFREC_AMD_FIFO_DEPTH (3): a caller may queue submits k+1 and k+2 before
+ * Submits and drains form a FIFO of depth TFREC_AMD_FIFO_DEPTH (4): a caller may queue submits k+1 .. k+3 before
  * draining submit k, so that the GPU works on them (front end of k+2, filter stage of k+1 and slicer/decoder stage of
- * k run beside each other) while the host copies and dispatches k's events; one more undrained submit is refused
- * with TFREC_AMD_E_STATE.  Alternating submit / drain behaves as one would expect. */
+ * k run beside each other, and the front end of k+3 is already queued when that of k+2 ends: with three, the front-end
+ * stream idled from then until the host had drained k and submitted again) while the host copies and dispatches k's
+ * events; one more undrained submit is refused with TFREC_AMD_E_STATE.  Every queued submit owns a full set of
+ * intermediate buffers (~7 GB at 1024 streams x 48 blocks).  Alternating submit / drain behaves as one would expect. */
 int tfrec_amd_drain_events(tfrec_amd_ctx *ctx, tfrec_amd_event *out, int cap, int *n_out);
 
 /* Number of events of the oldest undrained submit (waits for it). */

@@ -1,5 +1,5 @@
 """Randomised parity stress: random protocol masks, thresholds (incl. auto), filters, noise levels, submit splits and
-one to three submits in flight; every flush event of the GPU pipeline must equal the oracle's.
+one to four submits in flight; every flush event of the GPU pipeline must equal the oracle's.
     python tests/stress_gpu.py <seed> <rounds>      (tests/test_gpu_parity.py runs a short fixed campaign)"""
 import os
 import sys

@@ -195,10 +195,10 @@ def test_auto_threshold_matches_oracle(serial):
 
 
 def test_submits_in_flight_fifo():
-    """Submits k+1 and k+2 may be queued before submit k is drained (FIFO of depth three); a fourth one is refused."""
+    """Submits k+1 .. k+3 may be queued before submit k is drained (FIFO of depth four); a fifth one is refused."""
     n_streams = 6
     iq = synth.gen_batch(23, 5, n_streams, 40)
-    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 10), (10, 20), (20, 30), (30, 40))]
+    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 8), (8, 16), (16, 24), (24, 32), (32, 40))]
     with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=10, all_flushes=True) as r:
         ref = []
         for p in parts:
@@ -208,17 +208,15 @@ def test_submits_in_flight_fifo():
         import torch
         dev = [torch.from_numpy(p).cuda() for p in parts]
         got = []
-        assert api.FIFO_DEPTH == 3
-        r.submit(dev[0])
-        r.submit(dev[1])
-        r.submit(dev[2])
+        assert api.FIFO_DEPTH == 4
+        for k in range(4):
+            r.submit(dev[k])
         with pytest.raises(RuntimeError):
-            r.submit(dev[3])  # three submits are waiting to be drained
+            r.submit(dev[4])  # four submits are waiting to be drained
         got.append(r.drain())
-        r.submit(dev[3])
-        got.append(r.drain())
-        got.append(r.drain())
-        got.append(r.drain())
+        r.submit(dev[4])
+        for k in range(4):
+            got.append(r.drain())
         assert len(r.drain()) == 0
     for a, b in zip(ref, got):
         assert len(a) == len(b) and len(a) > 0
@@ -301,7 +299,7 @@ def test_tfa2_edge_timing_speculation_failure_is_resliced_exactly():
 def test_deep_and_shallow_layouts_agree_across_submits(monkeypatch):
     """Deep layout (six streams: the biquad stage of submit k+1 beside the slicers of submit k, two table sets) and
     shallow layout must give the same events as each other and as the oracle over a sequence of unequal submits kept
-    three deep in the FIFO."""
+    as deep in the FIFO as it goes."""
     n_streams, cuts = 6, (3, 1, 5, 2, 4, 1)
     iq = synth.gen_batch(77, 40, n_streams, sum(cuts), noise_q8=320)
     got = {}

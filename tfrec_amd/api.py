@@ -16,7 +16,7 @@ from . import _build
 BLOCK_BYTES = 65536
 BLOCK_DEC = 8192
 NSLOTS = 5
-FIFO_DEPTH = 3  # TFREC_AMD_FIFO_DEPTH
+FIFO_DEPTH = 4  # TFREC_AMD_FIFO_DEPTH
 SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
 
 F_ALL_FLUSHES = 1

@@ -120,7 +120,7 @@ namespace {
 //   reader thread : fread batch k+2 of every file into a pinned host buffer (three buffers in rotation)
 //   GPU           : H2D copy + hot path of batch k+1 (tfrec_amd_submit_host is asynchronous on pinned memory)
 //   worker thread : drain batch k's flush events and queue them for the engine's thread
-// The C ABI's submit/drain FIFO (depth TFREC_AMD_FIFO_DEPTH = 3) is what lets batch k+1 be queued before batch k is
+// The C ABI's submit/drain FIFO (depth TFREC_AMD_FIFO_DEPTH = 4) is what lets batch k+1 be queued before batch k is
 // drained; this loop keeps two in flight (the host side, not the GPU, bounds a file replay: DESIGN.md section 6).
 struct device_worker {
 	const std::vector<std::string> *files;
