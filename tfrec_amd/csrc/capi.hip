@@ -142,8 +142,8 @@ struct tfrec_amd_ctx {
 	// TFREC_AMD_E_STATE; destroy and recreate.
 	bool poisoned = false;
 	// TFREC_AMD_HOST_PROF=1: host-side time of the submit / drain calls, printed when the context is destroyed
-	double hp_submit = 0, hp_wait = 0, hp_copy = 0, hp_sort = 0;
-	long hp_n = 0;
+	double hp_submit = 0, hp_wait = 0, hp_copy = 0, hp_sort = 0, hp_gap = 0, hp_lat = 0, hp_s2s = 0;
+	long hp_n = 0, hp_gap_n = 0;
 };
 
 namespace {
@@ -254,6 +254,9 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		fprintf(stderr, "tfrec_amd host time per batch: submit %.0f us, drain: wait %.0f + copy %.0f + sort %.0f us (%ld batches)\n",
 			1e6 * c->hp_submit / c->hp_n, 1e6 * c->hp_wait / c->hp_n, 1e6 * c->hp_copy / c->hp_n, 1e6 * c->hp_sort / c->hp_n,
 			c->hp_n);
+	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_gap_n)
+		fprintf(stderr, "tfrec_amd front-end stream: %.3f ms between one submit's front end and the next one's; front-end start -> TFA_1 chain end %.2f ms; front-end start to start %.3f ms (%ld batches)\n",
+			c->hp_gap / c->hp_gap_n, c->hp_lat / c->hp_gap_n, c->hp_s2s / c->hp_gap_n, c->hp_gap_n);
 	(void)hipSetDevice(c->cfg.device);
 	(void)hipDeviceSynchronize();
 	for (int a = 0; a < kNSlots; a++)
@@ -1024,6 +1027,20 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	for (auto &e : c->done[set])
 		HIPCHK(hipEventSynchronize(e));
 	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[3]));
+	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_n > 2) {  // idle time of the front-end stream between two submits' front ends
+		float gap = 0, total = 0;
+		const int next = (set + 1) % kSets;  // (in flight: its front end started long ago)
+		if (hipEventElapsedTime(&gap, ev[3], c->ev[next][0]) == hipSuccess && hipEventElapsedTime(&total, ev[0], tev[20]) == hipSuccess &&
+		    gap > -1000 && gap < 1000) {
+			float s2s = 0;
+			if (hipEventElapsedTime(&s2s, ev[0], c->ev[next][0]) == hipSuccess)
+				c->hp_s2s += s2s;
+			c->hp_gap += gap;
+			c->hp_lat += total;
+			c->hp_gap_n++;
+		}
+		(void)hipGetLastError();
+	}
 	HIPCHK(hipEventElapsedTime(&out->fmdev_ms, ev[3], ev[1]));
 	if (c->need_fmdev && c->fmdev_k2 && !(c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS))
 		HIPCHK(hipEventElapsedTime(&out->fmdev_ms, tev[24], tev[25]));
