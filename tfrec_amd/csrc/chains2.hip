@@ -738,13 +738,17 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 	}
 }
 
-// K3c: see the K3 header.  A flat loop -- per iteration a lane either checks one segment (table look-ups) or
-// repairs one slot -- so that the lanes of a wave (different chains) never wait for each other's repairs.
+// K3c: see the K3 header.  Wave per chain.  The check of segment k -- "the last run that wrote k started from the true
+// state after k-1" -- only needs table entries once k-1 is known to be good, so all segments are checked at once, one
+// per lane; normally every check passes and the chain's new state is the last segment's end.  From the first segment
+// that fails, lane 0 walks on alone: a flat loop that per iteration either checks one segment or repairs one slot.
+// (As a lane-per-chain walk the kernel was a string of ~46 dependent table reads per chain; what remains of its time is
+// the longest serial repair of the batch -- a segment that did not converge behind one that did not either.)
 template <bool WHB>
 __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, const uint32_t *__restrict__ dec,
 					  size_t dec_stride, const int16_t *__restrict__ fmdev, size_t fmdev_stride,
 					  const ChainLaunch &L, const WinTables &T, int16_t *__restrict__ ld16,
-					  int32_t *__restrict__ dev32)
+					  int32_t *__restrict__ dev32, int lane)
 {
 	const int c = a * n_streams + s;
 	ChainState &st = L.states[a][s];
@@ -752,7 +756,8 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	if (vtotal == 0)
 		return;
 	const int nseg = (vtotal + kSegSlots - 1) / kSegSlots;
-	atomicAdd(&T.stats[0], (unsigned long long)nseg);
+	if (lane == 0)
+		atomicAdd(&T.stats[0], (unsigned long long)nseg);
 	const int count = T.count[c];
 	const BiquadCoef cf = L.params[a].iir;
 	const BiquadEnd *e1 = T.segend1 + (size_t)c * T.segcap;
@@ -760,9 +765,37 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
 	const uint32_t prev0 = T.prevdec[s];
 	const double2 *ckrow = T.ckpt + (size_t)c * T.slots;
-	BiquadEnd prev = e1[0], cur = prev;
-	Biquad f = biquad_of(prev);  // the TRUE state after segment 0
-	int k = 1;
+	// the end state of segment kk, IF the last run that wrote it started from the true state
+	auto end_if_good = [&](int kk) -> BiquadEnd {
+		if (kk == 0)
+			return e1[0];  // the speculative run of segment 0 starts from the carried state
+		const size_t sk = (size_t)c * T.segcap + kk;
+		const int fx2 = T.segfix2[sk];
+		const bool second = (fx2 & kSegRan) != 0;
+		const int fx = second ? fx2 : T.segfix[sk];
+		return (fx & kSegConverged) ? e1[kk] : (second ? T.segend3[sk] : T.segend2[sk]);
+	};
+	int k = nseg;  // the first segment whose last run did not start from the end of its predecessor
+	for (int base = 1; base < nseg; base += 64) {
+		const int kk = base + lane;
+		bool bad = false;
+		if (kk < nseg) {
+			const size_t sk = (size_t)c * T.segcap + kk;
+			const bool second = (T.segfix2[sk] & kSegRan) != 0;
+			const BiquadEnd from = second ? T.segend2[sk - 1] : e1[kk - 1];
+			const BiquadEnd t = end_if_good(kk - 1);
+			bad = !(same_bits(t.yn, from.yn) && same_bits(t.yn1, from.yn1) && same_bits(t.dn1, from.dn1) && same_bits(t.dn2, from.dn2));
+		}
+		const unsigned long long any = __ballot(bad);
+		if (any) {
+			k = base + __builtin_ctzll(any);
+			break;
+		}
+	}
+	if (lane != 0)
+		return;
+	Biquad f = biquad_of(end_if_good(k - 1));  // the TRUE state after segment k - 1
+	BiquadEnd prev = e1[k - 1], cur = prev;
 	bool repairing = false;
 	// repair state
 	int j = 0, i = 0, nslots = 0, min_slots = 0, done = 0, nsamples = 0;
@@ -841,20 +874,18 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 __global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
 							int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
-							int32_t *__restrict__ dev32, int lanes, int want_kind)
+							int32_t *__restrict__ dev32, int want_kind)
 {
 	const int a = blockIdx.y;
-	const int s = blockIdx.x * lanes + threadIdx.x;
-	if ((int)threadIdx.x >= lanes || s >= n_streams)
-		return;
+	const int s = blockIdx.x;  // wave per chain
 	const int M = n_blocks * kBlockDec;
 	const int kind = L.params[a].kind;
 	if (kind != want_kind)
 		return;
 	if (kind == 1)
-		fix_chain<false>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+		fix_chain<false>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32, (int)threadIdx.x);
 	else if (kind == 2)
-		fix_chain<true>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32);
+		fix_chain<true>(a, s, n_streams, M, dec, dec_stride, fmdev, fmdev_stride, L, T, ld16, dev32, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ slicers
@@ -2681,8 +2712,8 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(11, P.kw);
-		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
-				   L, T, ld16, dev32, lanes_chain, 2);
+		hipLaunchKernelGGL(fix_biquad_kernel, dim3(n_streams, L.n_active), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, 2);
 		mark(12, P.kw);
 		TRY(hipEventRecord(P.ev_kw, P.kw));
 		TRY(hipStreamWaitEvent(P.aux, P.ev_kw, 0));
@@ -2751,8 +2782,8 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(3, P.k2);
-		hipLaunchKernelGGL(fix_biquad_kernel, grid, block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride, n_streams, n_blocks,
-				   L, T, ld16, dev32, lanes_chain, 1);
+		hipLaunchKernelGGL(fix_biquad_kernel, dim3(n_streams, L.n_active), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, 1);
 		mark(4, P.k2);
 		TRY(hipEventRecord(P.ev_k2, P.k2));
 		TRY(hipStreamWaitEvent(P.cs, P.ev_k2, 0));
