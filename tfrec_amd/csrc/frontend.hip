@@ -40,16 +40,6 @@ __device__ __constant__ const int kS1[8] = { 2443, 6339, 11036, 14254, 14254, 11
 
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load, dword aligned
 
-__device__ __forceinline__ unsigned long long spread4(unsigned long long x)
-{
-	// bit i of the 16-bit input moves to bit 4*i
-	x = (x | (x << 24)) & 0x000000FF000000FFull;
-	x = (x | (x << 12)) & 0x000F000F000F000Full;
-	x = (x | (x << 6)) & 0x0303030303030303ull;
-	x = (x | (x << 3)) & 0x1111111111111111ull;
-	return x;
-}
-
 // IN16 = false: raw input is u8 IQ, x = (u8 - 128) << 6 (engine.cpp:77-78).  IN16 = true: the input already is
 // int16 (I,Q) pairs at 1.536 MS/s (what decim10_kernel produces for BASELINE config 5): 4 bytes per complex
 // sample instead of 2, per-tap (x*h)>>16 without the <<6 shortcut.
@@ -83,6 +73,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	// the next lane brought in; the 112 bytes before the submit come from the previous one's tail, what lies behind its
 	// end is silence (only the last tile's last groups look there, and their outputs are never used).
 	const long base = 8L * kB * m0 - kTail;
+	const bool interior = tile > 0 && tile + 1 < (int)gridDim.x;
 	const uint32_t silence = IN16 ? 0u : 0x80808080u;
 	auto raw_dword = [&](long bo) -> uint32_t {  // bo: byte offset into the stream, 4-byte aligned; edges only
 		if (bo >= 0 && bo + 4 <= nbytes)
@@ -102,9 +93,12 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
 		uint32_t rp[7 * kB];
 		{
-			const long bo = base + kB * (12 + 16 * grp);
-			if (bo >= 0 && bo + 28 * kB <= nbytes) {
-				const u32x4_u *g = reinterpret_cast<const u32x4_u *>(src + bo);
+			const int off = kB * (12 + 16 * grp);  // from `base`
+			// every tile but the submit's first and last reads inside the stream: no bounds to check (a wave-uniform branch;
+			// the 64-bit compares of the checked path were a tenth of the kernel's vector instructions)
+			if (interior || (base + off >= 0 && base + off + 28 * kB <= nbytes)) {
+				const uint8_t *gp = src + base + off;
+				const u32x4_u *g = reinterpret_cast<const u32x4_u *>(gp);
 #pragma unroll
 				for (int q = 0; q < (7 * kB) / 4; q++) {
 					const u32x4_u v = g[q];
@@ -112,11 +106,11 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 				}
 #pragma unroll
 				for (int q = 4 * ((7 * kB) / 4); q < 7 * kB; q++)
-					rp[q] = reinterpret_cast<const uint32_t *>(src + bo)[q];
+					rp[q] = reinterpret_cast<const uint32_t *>(gp)[q];
 			} else {
 #pragma unroll
 				for (int q = 0; q < 7 * kB; q++)
-					rp[q] = raw_dword(bo + 4 * q);
+					rp[q] = raw_dword(base + off + 4 * q);
 			}
 		}
 		f32x2 oy[4];
@@ -200,15 +194,20 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	*reinterpret_cast<uint4 *>(dec + (size_t)s * dec_stride + m0 + 4 * tid) =
 		make_uint4(outw[0], outw[1], outw[2], outw[3]);
 
-	// ---- trigger mask: bit b of word w <-> decimated sample 64*w + b
-	const unsigned long long b0 = __ballot(trig[0]), b1 = __ballot(trig[1]), b2 = __ballot(trig[2]),
-				 b3 = __ballot(trig[3]);
-	const int lane = tid & 63, wave = tid >> 6;
-	if (lane < 4) {
-		const int sh = 16 * lane;
-		const unsigned long long w = spread4((b0 >> sh) & 0xffff) | (spread4((b1 >> sh) & 0xffff) << 1) |
-					     (spread4((b2 >> sh) & 0xffff) << 2) | (spread4((b3 >> sh) & 0xffff) << 3);
-		mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + lane] = w;
+	// ---- trigger mask: bit b of word w <-> decimated sample 64*w + b.  Lane l holds samples 4*l .. 4*l+3 of its wave's
+	// 256: a nibble at bit 4*(l & 15) of word l >> 4.  Lanes 0-7 of a row of 16 fill the word's low dword, lanes 8-15 its
+	// high dword: shift the nibble within a dword, OR over the 8 lanes with three DPP steps, fetch the other half.
+	// (Built from four ballots with bit-spreading arithmetic this was a quarter of the kernel's vector instructions.)
+	{
+		const int lane = tid & 63, wave = tid >> 6;
+		const uint32_t nib = (uint32_t)trig[0] | ((uint32_t)trig[1] << 1) | ((uint32_t)trig[2] << 2) | ((uint32_t)trig[3] << 3);
+		uint32_t v = nib << (4 * (lane & 7));
+		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror: the other quad of the 8
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8: lane + 8's
+		if ((lane & 15) == 0)
+			mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + (lane >> 4)] = ((unsigned long long)hi << 32) | v;
 	}
 
 	// ---- the decimated sample BEFORE this submit's first one (it comes out of the carried raw history; zero history
