@@ -208,7 +208,8 @@ typedef struct {
 	uint64_t tfa2_resliced;      /* tfa2 windows sliced again because the last_bit_idx assumption did not hold */
 	uint64_t tfa1_recomputed;    /* 64-sample steps of long TFA_1 windows whose pre-computed peak detector piece did not
 				        start from the true value and were recomputed */
-	uint64_t reserved[3];
+	uint64_t biquad_repair_slots; /* 32-sample slots the first repair pass ran (a segment has up to 116) */
+	uint64_t reserved[2];
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
 /* Number of internal HIP streams the context's pipeline is laid out on: 6 = deep (default: the filter stage of submit

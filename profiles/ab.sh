@@ -8,7 +8,7 @@ cd $R
 libs="$R/tfrec_amd/libtfrec_amd.so $(ls $R/tfrec_amd/ab/*.so 2>/dev/null)"
 for r in $(seq $rounds); do
 	for lib in $libs; do
-		TFREC_AMD_LIB=$lib python bench.py --cpu-budget 0 --h2d-steps 0 --parity-streams 8 --steps 30 --warmup 5 "$@" 2>/dev/null | python -c "
+		TFREC_AMD_LIB=$lib python bench.py --cpu-budget 0 --h2d-steps 0 --parity-streams 8 --steps 30 --warmup 5 --no-extra-configs "$@" 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = j['roofline']['kernels_ms']

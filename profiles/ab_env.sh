@@ -6,7 +6,7 @@ shift
 cd $R
 for r in $(seq $rounds); do
 	for cfg in "$@"; do
-		env $cfg python bench.py --cpu-budget 0 --h2d-steps 0 --parity-streams 8 --steps 30 --warmup 5 2>/dev/null | python -c "
+		env $cfg python bench.py --cpu-budget 0 --h2d-steps 0 --parity-streams 8 --steps 30 --warmup 5 --no-extra-configs 2>/dev/null | python -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = j['roofline']['kernels_ms']

@@ -57,7 +57,8 @@ class Timings(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("biquad_segments", C.c_uint64), ("biquad_unconverged", C.c_uint64), ("biquad_serial", C.c_uint64),
-                ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("biquad_repair_slots", C.c_uint64),
+                ("reserved", C.c_uint64 * 2)]
 
 
 class FmStats(C.Structure):
@@ -265,7 +266,7 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:5]}
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:6]}
 
 
 def fm_dev_probe(records: np.ndarray, device: int = 0, cross: bool = False):

@@ -718,6 +718,7 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 					T.segend1[sk] = end_of(f);
 				} else if (MODE == 1) {
 					T.segfix[sk] = done | (conv ? kSegConverged : 0);
+					atomicAdd(&T.stats[5], (unsigned long long)done);
 					if (!conv) {
 						T.segend2[sk] = end_of(f);
 						atomicAdd(&T.stats[1], 1ull);
@@ -2671,6 +2672,12 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// biquad segments: at most (M/32 + windows)/kSegSlots + 1 per chain
 	const int seg_blocks = std::min(16384, (int)(((size_t)L.n_active * n_streams * ((size_t)n_blocks * (kBlockDec / 32) / kSegSlots + 4) +
 						       lanes_win - 1) / lanes_win));
+	// The repair passes run ~35 slots per segment on average, and the whole segment (116) for the few whose trajectories
+	// never meet: with a lane per segment a wave is as slow as its slowest lane and two thirds of its lanes idle.
+	// Several segments per lane instead (the flat loop of spec_biquad_kernel hands a lane the next one): a
+	// twelfth of the waves (3-4 segments per lane at 1024 streams); at least 256 so that small batches keep their parallelism.
+	static const int repair_div = env_int("TFREC_AMD_REPAIR_DIV", 12, 1, 64);
+	const int repair_blocks = std::min(seg_blocks, std::max(256, seg_blocks / repair_div));
 	// (few chains: the lanes of the lane-per-window kernels are mostly idle anyway and latency is all that counts)
 	static const int long_window_env = env_int("TFREC_AMD_COOP_MIN", 0, 0);
 	const int long_window = long_window_env >= 356 ? long_window_env
@@ -2707,9 +2714,9 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(10, P.kw);
-		hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(11, P.kw);
 		hipLaunchKernelGGL(fix_biquad_kernel, dim3(n_streams, L.n_active), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride,
@@ -2777,9 +2784,9 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 1>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 1>), dim3(repair_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(repair_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(3, P.k2);
 		hipLaunchKernelGGL(fix_biquad_kernel, dim3(n_streams, L.n_active), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride,
