@@ -223,6 +223,28 @@ def test_submits_in_flight_fifo():
         assert a.tobytes() == b.tobytes()
 
 
+def test_drain_fetches_events_beyond_the_copy_queued_at_submit(monkeypatch):
+    """The submit queues the device-to-host copy of a GUESSED number of events (twice the last drain's count); a batch
+    with more events than that must still deliver all of them, in the same order."""
+    n_streams = 6
+    iq = synth.gen_batch(29, 11, n_streams, 24)
+    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 2), (2, 14), (14, 24))]
+    out = {}
+    for guess in (None, "1"):
+        if guess:
+            monkeypatch.setenv("TFREC_AMD_COPY_GUESS_MIN", guess)
+        with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=12, all_flushes=True) as r:
+            for p in parts:  # queued together: the guesses of the 2nd and 3rd submit come from before the 1st drain
+                r.submit(p)
+            out[guess] = [r.drain() for _ in parts]
+    assert sum(len(e) for e in out[None]) > 50
+    for a, b in zip(out[None], out["1"]):
+        assert a.tobytes() == b.tobytes()
+    ev = np.concatenate(out["1"])
+    for s in range(n_streams):
+        check_stream(ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))], s, oracle_events(iq[s], 0x2F, 500))
+
+
 def test_config5_10x_front_end():
     """BASELINE config 5: 15.36 MS/s u8 input -> 10:1 integer FIR (defined by this project, oracle.decim10) ->
     the standard path on int16 input.  The 10:1 stage is checked bit for bit against its C restatement, everything

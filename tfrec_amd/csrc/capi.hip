@@ -115,7 +115,7 @@ struct tfrec_amd_ctx {
 	EventBuf *h_eb[kSets] = {};
 	hipEvent_t copied[kSets] = {};
 	uint32_t copied_n[kSets] = {};
-	uint32_t copy_guess = 4096;
+	uint32_t copy_guess = 4096, copy_guess_min = 4096;  // TFREC_AMD_COPY_GUESS_MIN (tests: exercise the fetch-the-rest path)
 	std::vector<uint32_t> sort_idx, sort_start;
 	hipEvent_t done[kSets][3] = {};  // end of the submit that owns the set, on the cs / aux / t1 stream
 	int head = 0, inflight = 0;           // oldest undrained set, submits not yet drained (0..TFREC_AMD_FIFO_DEPTH)
@@ -360,6 +360,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	c->cfg = *cfg;
 	if (const char *fe = getenv("TFREC_AMD_FM_FLAG_EPS"))
 		c->fm_flag_eps = std::max(1e-9, atof(fe));
+	if (const char *cg = getenv("TFREC_AMD_COPY_GUESS_MIN"))
+		c->copy_guess = c->copy_guess_min = (uint32_t)std::max(1, atoi(cg));
 	memset(&c->launch, 0, sizeof(c->launch));
 	memset(&c->win, 0, sizeof(c->win));
 
@@ -842,7 +844,7 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	if (have > c->copied_n[set])  // more events than the submit guessed (not on cp: the copies of younger submits wait there)
 		HIPCHK(hipMemcpy(tmp + c->copied_n[set], c->d_events[set] + c->copied_n[set],
 				 (size_t)(have - c->copied_n[set]) * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost));
-	c->copy_guess = std::max<uint32_t>(4096u, 2 * have);
+	c->copy_guess = std::max<uint32_t>(c->copy_guess_min, 2 * have);
 	c->head = (c->head + 1) % kSets;
 	c->inflight--;
 	c->last_drained = set;
