@@ -19,7 +19,8 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
-        names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("tfrec::", "")
+        nm = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tfrec::", "")
+        names[r["Dispatch_Id"]] = nm if nm.startswith("spec_biquad_kernel") else nm.split("<")[0]  # the six biquad passes apart
     for d_id, v in per_dispatch.items():
         acc[names[d_id]].append(v)
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}

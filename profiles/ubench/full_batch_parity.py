@@ -1,4 +1,4 @@
-"""The bench batch (1024 distinct streams x 48 blocks, all protocols), three batches deep: every flush event of the
+"""The bench batch (1024 distinct streams x 48 blocks, all protocols), five batches through the four-deep FIFO: every flush event of the
 window-parallel pipeline must equal the one of the independent serial lane-per-chain GPU implementation."""
 import sys
 import numpy as np
@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 from tfrec_amd import api, synth
 
 ns, nb = 1024, 48
-d = [torch.from_numpy(synth.gen_batch(1000 + 17 * k, 0, ns, nb)).cuda() for k in range(3)]
+d = [torch.from_numpy(synth.gen_batch(1000 + 17 * k, 0, ns, nb)).cuda() for k in range(5)]
 out = {}
 for serial in (False, True):
     with api.Receiver(ns, 0x2F, 500, 0, max_blocks=nb, all_flushes=True, serial_chains=serial, max_events=ns * 400) as r:
@@ -17,12 +17,16 @@ for serial in (False, True):
                 r.submit(x)
                 evs.append(r.drain())
         else:
-            for x in d:
+            evs = []
+            for k, x in enumerate(d):
+                if k >= api.FIFO_DEPTH:
+                    evs.append(r.drain())
                 r.submit(x)
-            evs = [r.drain() for _ in d]
+            while len(evs) < len(d):
+                evs.append(r.drain())
         assert r.atan_uncertain() == 0
         out[serial] = evs
-for k in range(3):
+for k in range(len(d)):
     a, b = out[False][k], out[True][k]
     print("batch %d: %d events, equal: %s" % (k, len(a), a.tobytes() == b.tobytes()))
     assert a.tobytes() == b.tobytes()
