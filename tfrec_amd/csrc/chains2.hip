@@ -533,6 +533,17 @@ __device__ __forceinline__ SegWin seg_win(const WinTables &T, int c, int j, int 
 
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
 
+// Checkpoints of the speculative pass are kept for every kCkEvery-th slot (by slot number, so every pass agrees on
+// which): a repair run can only join the speculative trajectory there, up to kCkEvery - 1 slots later than with a
+// checkpoint per slot (~35 slots per run on average), for a quarter of the 16-byte lane-per-row checkpoint stores and
+// loads -- partial-line accesses, the expensive kind (section 7c).
+#ifndef TFREC_AMD_CK_EVERY
+#define TFREC_AMD_CK_EVERY 4
+#endif
+constexpr int kCkEvery = TFREC_AMD_CK_EVERY;
+static_assert((kCkEvery & (kCkEvery - 1)) == 0, "a power of two");
+__device__ __forceinline__ bool ck_slot(int slot) { return (slot & (kCkEvery - 1)) == kCkEvery - 1; }
+
 // Run the biquad over `nslots` consecutive in-window slots of chain c, starting at slot i of window j (the run
 // hops to the following windows as they end).  REPAIR = false: speculative run, stores outputs and checkpoints.
 // REPAIR = true: stores outputs and stops after the first slot (>= min_slots slots, >= 2 samples in) whose end
@@ -612,7 +623,7 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 	auto fetch = [&](K3Chunk<WHB> &buf, double2 &ck) {
 		if (loaded < nslots) {
 			k3_load<WHB>(buf, in, pl.w.og + kChunk * pl.i, prev0);
-			if (REPAIR)
+			if (REPAIR && ck_slot(pl.w.slot0 + pl.i))
 				ck = ckrow[pl.w.slot0 + pl.i];
 			loaded++;
 			if (loaded < nslots)
@@ -707,11 +718,14 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 			nsamples += nv;
 			done++;
 			bool conv = false;
-			if (!REPAIR)
-				ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
-			else  // the state equals the speculative checkpoint bit for bit (the two last inputs are then shared too): from
-			      // here on the stored trajectory is the continuation of this run
-				conv = same_bits(f.yn, ckA.x) && same_bits(f.yn1, ckA.y) && nsamples >= 2 && done >= min_slots;
+			const bool at_ck = ck_slot(pp.w.slot0 + pp.i);
+			if (!REPAIR) {
+				if (at_ck)
+					ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
+			} else {  // the state equals the speculative checkpoint bit for bit (the two last inputs are then shared too):
+				  // from here on the stored trajectory is the continuation of this run
+				conv = at_ck && same_bits(f.yn, ckA.x) && same_bits(f.yn1, ckA.y) && nsamples >= 2 && done >= min_slots;
+			}
 			if (conv || done >= nslots) {
 				busy = false;
 				if (MODE == 0) {
@@ -834,7 +848,7 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 			cw = seg_win(T, c, j, M);
 			nw = seg_win(T, c, j + 1 < count ? j + 1 : j, M);
 			k3_load<WHB>(A, in, cw.og + kChunk * i, prev0);
-			ckA = ckrow[cw.slot0 + i];
+			ckA = ckrow[cw.slot0 + i];  // (read for every slot, used at checkpoint slots only)
 			repairing = true;
 		}
 		// one slot of the repair run (cf. seg_run<.., true>)
@@ -851,7 +865,8 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 		k3_store<WHB>(out, cw.slot0 + i, ow);
 		nsamples += nv;
 		done++;
-		const bool joined = same_bits(f.yn, ckA.x) && same_bits(f.yn1, ckA.y) && nsamples >= 2 && done >= min_slots;
+		const bool joined = ck_slot(cw.slot0 + i) && same_bits(f.yn, ckA.x) && same_bits(f.yn1, ckA.y) && nsamples >= 2 &&
+				    done >= min_slots;
 		if (joined || !more) {
 			if (joined)
 				f = biquad_of(cur);  // joined the speculative trajectory: its end state is the true one
@@ -2678,6 +2693,13 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// twelfth of the waves (3-4 segments per lane at 1024 streams); at least 256 so that small batches keep their parallelism.
 	static const int repair_div = env_int("TFREC_AMD_REPAIR_DIV", 12, 1, 64);
 	const int repair_blocks = std::min(seg_blocks, std::max(256, seg_blocks / repair_div));
+	// The speculative pass with an eighth of the worst-case waves (~1000 at 1024 streams: 2-3 segments per lane).  A lane
+	// reads 64 (+4) bytes per slot at an arbitrary 2-byte offset of its row, so consecutive slots share a 128-byte line;
+	// with a lane per segment the lines in flight (2540 waves x 64 lanes x 2 lines = 40 MB) never survived in the 32 MB
+	// of L2 until the lane came back: the pass fetched 2.9 GB for 1.1 GB of input.  With ~1000 waves: 1.4 GB, and the
+	// batch 2 % shorter.  (A sixteenth starves the WHB chain.)
+	static const int spec_div = env_int("TFREC_AMD_SPEC_DIV", 8, 1, 64);
+	const int spec_blocks = std::min(seg_blocks, std::max(256, seg_blocks / spec_div));
 	// (few chains: the lanes of the lane-per-window kernels are mostly idle anyway and latency is all that counts)
 	static const int long_window_env = env_int("TFREC_AMD_COOP_MIN", 0, 0);
 	const int long_window = long_window_env >= 356 ? long_window_env
@@ -2711,7 +2733,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	if (has_whb) {
 		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
 		mark(9, P.kw);
-		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(seg_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(spec_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(10, P.kw);
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
@@ -2774,7 +2796,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			mark(25, P.k2);
 		}
 		mark(1, P.k2);
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(seg_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(2, P.k2);
 		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
