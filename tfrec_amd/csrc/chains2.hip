@@ -162,6 +162,10 @@ hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stri
 __global__ __launch_bounds__(64) void windows_kernel(const unsigned long long *__restrict__ mask, size_t mask_stride,
 						     int n_streams, int n_blocks, ChainLaunch L, WinTables T, int long_window)
 {
+	// The small kernels between the big passes (scan, verify, decode, commit: a few hundred waves of table work) issue
+	// ahead of the throughput kernels they share a SIMD with: they cost those nothing measurable and every one of them
+	// stands in a stream's chain (-1 % per batch).
+	__builtin_amdgcn_s_setprio(3);
 	const int s = blockIdx.x;
 	const int lane = threadIdx.x;
 	const int M = n_blocks * kBlockDec;
@@ -892,6 +896,7 @@ __global__ __launch_bounds__(64) void fix_biquad_kernel(const uint32_t *__restri
 							int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
 							int32_t *__restrict__ dev32, int want_kind)
 {
+	__builtin_amdgcn_s_setprio(3);  // see windows_kernel
 	const int a = blockIdx.y;
 	const int s = blockIdx.x;  // wave per chain
 	const int M = n_blocks * kBlockDec;
@@ -2427,6 +2432,7 @@ __device__ __forceinline__ void decode_window(int c, int j, int n_streams, const
 
 __global__ __launch_bounds__(64) void decode_kernel(int n_streams, ChainLaunch L, WinTables T, int kind)
 {
+	__builtin_amdgcn_s_setprio(3);  // see windows_kernel
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
 	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
@@ -2614,6 +2620,7 @@ __global__ __launch_bounds__(64) void commit_kernel(const uint32_t *__restrict__
 						    tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags,
 						    int lanes, int want_kind)
 {
+	__builtin_amdgcn_s_setprio(3);  // see windows_kernel
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[64 * 256];
 	uint8_t *my_rdata = rdata_lds + 256 * threadIdx.x;
 	const int a = blockIdx.y;
@@ -2636,6 +2643,7 @@ __global__ __launch_bounds__(64) void commit_wave_kernel(const uint32_t *__restr
 							 tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb,
 							 uint32_t flags)
 {
+	__builtin_amdgcn_s_setprio(3);  // see windows_kernel
 	__shared__ __attribute__((aligned(16))) uint8_t rdata_lds[256];
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const uint32_t count = T.queue[kDeferQueue].count;
