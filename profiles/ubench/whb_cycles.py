@@ -23,7 +23,7 @@ with api.Receiver(ns, mask, 500, 0, max_blocks=nb, max_events=1 << 20) as r:
             r.submit(d); r.drain()
     st = api.Stats()
     r.L.tfrec_amd_get_stats(r.h, C.byref(st))
-    raw = [int(x) for x in (st.tfa1_recomputed, *st.reserved)]
+    raw = [int(x) for x in (st.tfa1_recomputed, st.biquad_repair_slots, *st.reserved)]
     span = [int(st.biquad_unconverged), int(st.biquad_serial), int(st.tfa2_resliced)]
 steps, usteps = raw[0] >> 32, raw[0] & 0xffffffff
 print("per stream and submit: steps %.0f, with recurrence %.0f" % (steps / ns / nsub, usteps / ns / nsub))

@@ -736,7 +736,9 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 					T.segend1[sk] = end_of(f);
 				} else if (MODE == 1) {
 					T.segfix[sk] = done | (conv ? kSegConverged : 0);
+#ifndef TFREC_AMD_PROFILE_WHB  // (that build counts the WHB demodulator's cycles in this slot)
 					atomicAdd(&T.stats[5], (unsigned long long)done);
+#endif
 					if (!conv) {
 						T.segend2[sk] = end_of(f);
 						atomicAdd(&T.stats[1], 1ull);
