@@ -146,11 +146,25 @@ def main():
     a = ap.parse_args()
     rate = 10 if a.input_10x else 1
 
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, as the driver's
+        # torch.distributed.run command line does) instead of silently measuring one rank
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    if world != a.gpus:  # never report a line for another job size than the one asked for
+        sys.exit("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE)" % (a.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -165,6 +179,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != a.gpus:
+            sys.exit("bench.py: %d ranks met at the rendezvous, --gpus %d" % (dist.get_world_size(), a.gpus))
     red_dev = dev if (world > 1 and a.dist_backend == "nccl") else None  # where the reduced scalars live
 
     n_streams, n_blocks = a.streams, a.blocks
@@ -327,7 +343,7 @@ def main():
                 first = xr_.drain()
                 ok = True
                 minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
-                for k in range(min(2, xu)):
+                for k in range(xu):  # every distinct stream of the leg's batch
                     o = O.Oracle(xt, a.thresh, 0)
                     if x10:
                         o.process_s16(O.decim10(xh[k]))
@@ -350,6 +366,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - tx
             extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, input_10x=x10, steps=steps, parity_ok=ok,
+                               parity_streams_checked=xu,
                                ms_per_step=round(dt / steps * 1e3, 4),
                                value=round(xs * xb * SAMPLES_PER_BLOCK * xr * steps / dt / 1e6, 1), unit="MSamples/s")
 

@@ -61,3 +61,16 @@ def test_bench_two_ranks_gloo_on_one_device():
     assert c["events_all_ranks"] > c["events_per_step"] * j["steps"]  # both ranks' events counted
     # value is the whole job: both ranks' samples over the slowest rank's time
     assert abs(j["value"] - 2 * 64 * 8 * 32768 * j["steps"] / (j["ms_per_step"] * j["steps"] * 1e-3) / 1e6) / j["value"] < 1e-3
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no RANK / WORLD_SIZE in the environment): bench.py starts the two ranks itself
+    through torch.distributed.run and reports n_gpus = the ranks that really ran (it used to run ONE rank and
+    print n_gpus 1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--dist-backend",
+                          "gloo"] + COMMON, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _line(out.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["parity_ok"] is True
+    assert len(j["config"]["rank_input_crc32"]) == 2

@@ -473,6 +473,20 @@ def test_quarter_of_config2_every_stream_against_the_oracle():
         assert r.fm_stats()["host_mismatch"] == 0
 
 
+def test_config2_full_size_every_stream():
+    """BASELINE configs[2] at its full size: 1024 streams x 48 blocks x all five protocols in ONE submit (the shape
+    bench.py times), every stream's complete flush log (TFREC_AMD_F_ALL_FLUSHES) against the oracle."""
+    n_streams, n_blocks = 1024, 48
+    iq = synth.gen_batch(1000, 0, n_streams, n_blocks)
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True, max_events=n_streams * n_blocks * 40) as r:
+        r.submit(iq)
+        ev = r.drain()
+        total = _all_streams_equal(ev, iq, 0x2F, 500)
+        assert total > 80 * n_streams
+        assert r.fm_stats()["host_mismatch"] == 0
+        assert r.stats()["biquad_segments"] > 100 * n_streams
+
+
 def test_hostile_and_degenerate_inputs_over_ragged_submits():
     """Inputs a receiver must survive, each against the oracle, in one batch cut into submits of 1, 2, 5 and 3 blocks: pure
     silence (no window at all), full-scale DC (0x00 / 0xff: the trigger never releases, the discriminator sits on its
@@ -498,7 +512,6 @@ def test_hostile_and_degenerate_inputs_over_ragged_submits():
         for s in range(len(iq)):
             o = oracle_events(iq[s], 0x2F, 500)
             check_stream(ev, s, o)
-            want_dec = np.empty(2 * n_blocks * 8192, dtype=np.int16)
         assert len(api.event_tuples(ev, 0)) == 0  # silence: nothing at all
         assert r.fm_stats()["host_mismatch"] == 0
 
