@@ -425,6 +425,8 @@ def main():
                 "parity_ok": parity_ok, "gen_seconds": round(t_gen, 2),
                 "atan_resolved": fm["resolved"], "atan_host_verified": fm["host_verified"],
                 "atan_host_mismatch": fm_bad, "atan_undecidable": fm["undecidable"],
+                # slow-path decisions beyond the per-submit log (62): exact by construction, but not compared with this host's libm
+                "atan_unverified": fm["resolved"] - fm["host_verified"],
                 "dist_backend": a.dist_backend if world > 1 else None,
                 "rank_input_crc32": input_crc, "events_all_ranks": events_all,
             },
@@ -449,6 +451,9 @@ def main():
             out["other_configs"] = extra
         print(json.dumps(out), flush=True)
     r.close()
+    if rank == 0 and fm["undecidable"]:
+        print("fm_dev: %d sample(s) within 0.06 ulp of an atan2 rounding midpoint: glibc's own result there is host-dependent"
+              % fm["undecidable"], file=sys.stderr)
     if fm_bad:
         print("fm_dev: %d slow-path decisions differ from this host's libm" % fm_bad, file=sys.stderr)
         if world > 1:

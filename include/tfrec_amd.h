@@ -33,9 +33,8 @@ extern "C" {
 #endif
 
 #define TFREC_AMD_BLOCK_BYTES 65536 /* RLS, engine.cpp:68 */
-#ifndef TFREC_AMD_FIFO_DEPTH
-#define TFREC_AMD_FIFO_DEPTH 4  /* submits that may wait to be drained (tfrec_amd_drain_events) */
-#endif
+#define TFREC_AMD_FIFO_DEPTH 4  /* submits that may wait to be drained (tfrec_amd_drain_events); a property of the built
+				   library: tfrec_amd_fifo_depth() reports the value it was compiled with */
 #define TFREC_AMD_BLOCK_BYTES_10X 655360 /* one block of a 15.36 MS/s stream (TFREC_AMD_F_INPUT_10X) */
 #define TFREC_AMD_BLOCK_DEC 8192    /* decimated IQ pairs per block (4:1, dsp_stuff.cpp:243-264) */
 #define TFREC_AMD_NSLOTS 5
@@ -115,6 +114,9 @@ typedef struct {
 } tfrec_amd_timings;
 
 const char *tfrec_amd_version(void);
+/* TFREC_AMD_FIFO_DEPTH of the loaded library (every submit in flight owns a full set of intermediate buffers: about
+ * 7 GB per set and context at 1024 streams x 48 blocks -- several contexts on one device multiply that). */
+int tfrec_amd_fifo_depth(void);
 const char *tfrec_amd_strerror(int code);
 /* text of the last HIP error seen by this thread ("" if none) */
 const char *tfrec_amd_last_error(void);

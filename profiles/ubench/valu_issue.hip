@@ -103,8 +103,7 @@ static void run(const char *name, int W, int n_cu)
 	const int blocks = n_cu * W;
 	unsigned long long *d_t;
 	float *sink;
-	hipMalloc(&d_t, blocks * 4 * 2 * sizeof(unsigned long long));
-	hipMalloc(&sink, 4);
+	if (hipMalloc(&d_t, blocks * 4 * 2 * sizeof(unsigned long long)) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); exit(1); }
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0);
 	hipEventCreate(&e1);
@@ -113,7 +112,7 @@ static void run(const char *name, int W, int n_cu)
 	hipEventRecord(e0);
 	hipLaunchKernelGGL(issue_kernel<CLS>, dim3(blocks), dim3(256), 0, 0, d_t, reps, sink);
 	hipEventRecord(e1);
-	hipDeviceSynchronize();
+	{ hipError_t e_ = hipDeviceSynchronize(); if (e_ != hipSuccess) { fprintf(stderr, "%s W=%d: %s\n", name, W, hipGetErrorString(e_)); exit(1); } }
 	float ms = 0;
 	hipEventElapsedTime(&ms, e0, e1);
 	std::vector<unsigned long long> t(blocks * 8);
@@ -133,8 +132,11 @@ static void run(const char *name, int W, int n_cu)
 	hipFree(sink);
 }
 
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
 int main()
 {
+	setvbuf(stdout, NULL, _IONBF, 0);
 	hipDeviceProp_t p;
 	hipGetDeviceProperties(&p, 0);
 	const int n_cu = p.multiProcessorCount;

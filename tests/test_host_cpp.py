@@ -175,3 +175,38 @@ def test_reference_linked_cli_replays_a_dump(golden_dir, tmp_path):
     want = [ln for ln in c["text"].splitlines() if ln != "Inverted SYNC"]
     got = [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("WHB: Samples")]
     assert got == want
+
+
+@pytest.mark.gpu
+def test_bits_replay_reproduces_what_store_bit_prints(cli, golden_dir, tmp_path):
+    """SURVEY 8b, BITS mode: `tfrec_gpu -B` hands every demodulated bit to the decoder's own store_bit and replays every
+    flush; stdout is then the reference's complete text INCLUDING the "Inverted SYNC" lines of tfa2_decoder::store_bit
+    (tfa2.cpp:294-300) -- for the mirror decoders and for the adapter linked with the reference's unchanged objects.
+    Streams with I/Q swapped (inverted FSK polarity), goldens from the real reference (oracle/mint_inverted.py)."""
+    from tfrec_amd import synth
+    cases = json.load(open(os.path.join(golden_dir, "inverted_sync.json")))["cases"]
+    clis = [cli]
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "tfrec_gpu_ref")
+    if os.path.exists(ref_cli):
+        clis.append(ref_cli)
+    files = []
+    for k, c in enumerate(cases):
+        iq = synth.gen_stream(c["seed"], c["stream"], c["n_blocks"], c["proto_mask"], c["noise_q8"])
+        iq = iq.reshape(-1, 2)[:, ::-1].reshape(-1).copy()
+        p = tmp_path / ("inv%d.iq" % k)
+        iq.tofile(p)
+        files.append(str(p))
+    for exe in clis:
+        for c, f in zip(cases, files):
+            want = [ln for ln in c["text"].splitlines() if ln.strip()]
+            assert want.count("Inverted SYNC") >= 3
+            for blocks in ("5", "24"):  # windows cut by submits / one submit
+                out = subprocess.run([exe, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-b", blocks, "-B", "-L", f],
+                                     capture_output=True, text=True, check=True).stdout
+                got = [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("WHB: Samples")]
+                assert got == want, (exe, blocks)
+            # the byte-level replay prints the same telegrams, without store_bit's own line
+            out = subprocess.run([exe, "-T", "%x" % c["types"], "-t", str(c["thresh"]), "-b", "5", "-L", f],
+                                 capture_output=True, text=True, check=True).stdout
+            got = [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("WHB: Samples")]
+            assert got == [ln for ln in want if ln != "Inverted SYNC"]

@@ -72,6 +72,26 @@ def test_synthetic_streams_against_reference_outputs(golden_dir):
         assert o.text() == c["text"]
 
 
+def _inverted_iq(c):
+    iq = synth.gen_stream(c["seed"], c["stream"], c["n_blocks"], c["proto_mask"], c["noise_q8"])
+    return iq.reshape(-1, 2)[:, ::-1].reshape(-1).copy() if c.get("iq_swap") else iq
+
+
+def test_inverted_polarity_streams_against_reference_outputs(golden_dir):
+    """I/Q swapped: the TFA_2-family decoders lock on the complemented sync word (tfa2.cpp:294-300); text incl. the
+    "Inverted SYNC" lines, flush events and the store_bit log of the real reference (oracle/mint_inverted.py)."""
+    cases = json.load(open(os.path.join(golden_dir, "inverted_sync.json")))["cases"]
+    for c in cases:
+        iq = _inverted_iq(c)
+        assert _sha(iq) == c["iq_sha256"]
+        o = O.Oracle(c["types"], c["thresh"], c["wide"], log_bits=True)
+        assert o.process(iq) == c["n_blocks"]
+        assert o.events() == _events(c["events"])
+        assert o.data() == _data(c["data"])
+        assert o.text() == c["text"] and c["text"].count("Inverted SYNC") >= 3
+        assert o.bits_text() == c["bits"]
+
+
 def test_config5_int16_entry_against_reference_outputs(golden_dir):
     """BASELINE config 5: 15.36 MS/s input -> 10:1 stage (defined by this project) -> the reference's int16 entry."""
     cases = json.load(open(os.path.join(golden_dir, "config5.json")))["cases"]

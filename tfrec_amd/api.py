@@ -88,6 +88,7 @@ EXPORTS = (
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
     "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_get_layout", "tfrec_amd_host_alloc",
     "tfrec_amd_host_free", "tfrec_amd_read_stage0", "tfrec_amd_get_fm_stats", "tfrec_amd_fm_dev_probe",
+    "tfrec_amd_fifo_depth",
 )
 
 _lib = None
@@ -140,6 +141,10 @@ def load_library(build: bool = True):
     L.tfrec_amd_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.tfrec_amd_get_fm_stats.argtypes = [C.c_void_p, C.POINTER(FmStats)]
     L.tfrec_amd_fm_dev_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(FmStats)]
+    L.tfrec_amd_fifo_depth.restype = C.c_int
+    if L.tfrec_amd_fifo_depth() != FIFO_DEPTH:
+        raise RuntimeError("libtfrec_amd.so was built with FIFO depth %d, this binding expects %d" % (
+            L.tfrec_amd_fifo_depth(), FIFO_DEPTH))
     _lib = L
     return L
 
@@ -285,7 +290,6 @@ def events_canon(events: np.ndarray):
     """Vector form of event_tuples for whole batches: (stream[n], int64 matrix [n, 5 + 64] with the columns slot,
     end_sample, byte_cnt, rssi_db, offset, rdata) -- the layout of oracle.canon()."""
     L = load_library()
-    m = np.empty((len(events), 69), dtype=np.int64)
     events = events[events["status"] != STATUS_BITS]
     m = np.empty((len(events), 69), dtype=np.int64)
     m[:, 0] = events["slot"]

@@ -223,6 +223,8 @@ extern "C" {
 
 const char *tfrec_amd_version(void) { return "tfrec_amd 0.1 (gfx950)"; }
 
+int tfrec_amd_fifo_depth(void) { return kSets; }
+
 const char *tfrec_amd_strerror(int code)
 {
 	switch (code) {
@@ -476,7 +478,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
 		ALLOC(c->d_ld16[set], chains * (size_t)T.slots * 32 * sizeof(int16_t));
 		if (whb)
-			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t) + 1024);  // + slack: whb_demod128 loads whole steps
+			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t) + 1024);  // + slack: whb_demod_kernel keeps two 64-sample steps in flight past a row's last window
 		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
 		const size_t wins = chains * (size_t)T.cap;
 		size_t off = 0;
@@ -754,7 +756,18 @@ int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, i
 	return rc;
 }
 
+static int submit_host_impl(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks);
+
 int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = submit_host_impl(c, h_iq, stride, n_blocks);
+	if (c)
+		c->hp_submit += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return rc;
+}
+
+static int submit_host_impl(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks)
 {
 	if (!c || !h_iq || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
 		return TFREC_AMD_E_INVAL;
@@ -812,6 +825,10 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 	if (!c || !n)
 		return TFREC_AMD_E_INVAL;
 	*n = 0;
+	if (c->poisoned) {  // (copied[head] may never have been recorded: synchronising on it would succeed at once)
+		snprintf(g_err, sizeof(g_err), "an earlier submit failed half way: the context must be recreated");
+		return TFREC_AMD_E_STATE;
+	}
 	if (c->inflight == 0)
 		return TFREC_AMD_OK;
 	HIPCHK(hipSetDevice(c->cfg.device));
@@ -934,6 +951,8 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 {
 	if (!c || !n)
 		return TFREC_AMD_E_INVAL;
+	if (c->poisoned)
+		return TFREC_AMD_E_STATE;
 	int rc = tfrec_amd_sync(c);
 	if (rc)
 		return rc;
@@ -950,6 +969,8 @@ int tfrec_amd_get_fm_stats(tfrec_amd_ctx *c, tfrec_amd_fm_stats *out)
 {
 	if (!c || !out)
 		return TFREC_AMD_E_INVAL;
+	if (c->poisoned)
+		return TFREC_AMD_E_STATE;
 	memset(out, 0, sizeof(*out));
 	out->resolved = c->fm.resolved;
 	out->host_verified = c->fm.verified;

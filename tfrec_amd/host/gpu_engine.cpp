@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -27,7 +28,7 @@ void tfrec_handler_args(const sensordata_t &d, sensor_e dec_type, char *out, siz
 gpu_engine::gpu_engine(const std::vector<std::string> &dumpfiles, int _types, int _thresh, int _filter, int _dbg,
 		       const std::vector<int> &_devices, int blocks_per_submit)
 	: files(dumpfiles), types(_types), thresh(_thresh), filter(_filter), dbg(_dbg), bps(blocks_per_submit),
-	  devices(_devices), n_telegrams(0), sink(NULL), psink(NULL), out_mode(0)
+	  devices(_devices), n_telegrams(0), sink(NULL), psink(NULL), out_mode(0), bits_replay(false)
 {
 	if (devices.empty())
 		devices.push_back(0);
@@ -97,17 +98,26 @@ gpu_engine::~gpu_engine()
 
 // The adapter contract: bring the decoder's rdata[0..64) to the state the GPU decoder had,
 // set byte_cnt, then let the unchanged handler do CRC, parsing, printing, store_data.
+// BITS mode: the decoder receives every bit through its own store_bit (decoder.h:39) -- it then holds rdata / byte_cnt
+// by itself, and whatever store_bit prints appears as in the reference -- and every flush, without store_bytes.
 void gpu_engine::replay(const tfrec_amd_event &ev)
 {
 	decoder *dec = decs[ev.stream][ev.slot];
 	if (!dec)
 		return;
-	uint8_t buf[256];
-	memset(buf, 0, sizeof(buf));
-	memcpy(buf, ev.rdata, 64);
-	dec->store_bytes(buf, 64);
-	int len = ev.byte_cnt > 256 ? 256 : ev.byte_cnt;
-	dec->store_bytes(buf, len);
+	if (ev.status == TFREC_AMD_STATUS_BITS) {
+		for (int k = 0; k < (int)ev.byte_cnt && k < 512; k++)
+			dec->store_bit((ev.rdata[k >> 3] >> (k & 7)) & 1);
+		return;
+	}
+	if (!bits_replay) {
+		uint8_t buf[256];
+		memset(buf, 0, sizeof(buf));
+		memcpy(buf, ev.rdata, 64);
+		dec->store_bytes(buf, 64);
+		int len = ev.byte_cnt > 256 ? 256 : ev.byte_cnt;
+		dec->store_bytes(buf, len);
+	}
 	dec->flush(tfrec_amd_rssi_db(ev.slot, ev.rssi_raw), ev.offset);
 	if (ev.status == 1)
 		n_telegrams++;
@@ -120,21 +130,23 @@ namespace {
 //   reader thread : fread batch k+2 of every file into a pinned host buffer (three buffers in rotation)
 //   GPU           : H2D copy + hot path of batch k+1 (tfrec_amd_submit_host is asynchronous on pinned memory)
 //   worker thread : drain batch k's flush events and queue them for the engine's thread
-// The C ABI's submit/drain FIFO (depth TFREC_AMD_FIFO_DEPTH = 4) is what lets batch k+1 be queued before batch k is
-// drained; this loop keeps two in flight (the host side, not the GPU, bounds a file replay: DESIGN.md section 6).
+// The C ABI's submit/drain FIFO (depth TFREC_AMD_FIFO_DEPTH = 4) is what lets batches k+1 .. k+3 be queued before batch
+// k is drained; this loop keeps the FIFO full (one pinned host buffer per submit in flight + one being read).
 struct device_worker {
 	const std::vector<std::string> *files;
 	size_t s0, s1;
 	int device, types, thresh, filter, bps;
+	uint32_t flags;     // TFREC_AMD_F_* of the context
 	size_t max_blocks;  // of ALL files: every device runs the same number of batches
 	int rc;
+	std::atomic<bool> *abort;  // set by the engine when any worker failed: stop instead of running the whole job
 	std::mutex mu;
 	std::condition_variable cv;
 	std::deque<std::vector<tfrec_amd_event> > out;  // batches drained, oldest first
 	bool done;
 	std::thread th;
 
-	device_worker() : files(NULL), s0(0), s1(0), device(0), types(0), thresh(0), filter(0), bps(1), max_blocks(0), rc(0), done(false) {}
+	device_worker() : files(NULL), s0(0), s1(0), device(0), types(0), thresh(0), filter(0), bps(1), flags(0), max_blocks(0), rc(0), abort(NULL), done(false) {}
 
 	void push(std::vector<tfrec_amd_event> &&ev)
 	{
@@ -190,8 +202,9 @@ struct device_worker {
 		cfg.filter_type = filter;
 		cfg.device = device;
 		cfg.max_blocks = bps;
-		cfg.max_events = (int32_t)std::max<size_t>(4096, n * (size_t)bps * 64);
-		cfg.flags = 0;
+		// (BITS mode: every flush + a chunk per 512 bits, a slicer emits < 0.5 bit per decimated sample)
+		cfg.max_events = (int32_t)std::max<size_t>(4096, n * (size_t)bps * ((flags & TFREC_AMD_F_BITS) ? 256 : 64));
+		cfg.flags = flags;
 		tfrec_amd_ctx *ctx = NULL;
 		int r = tfrec_amd_create(&cfg, &ctx);
 		if (r) {
@@ -202,7 +215,8 @@ struct device_worker {
 		}
 		const size_t row = (size_t)bps * TFREC_AMD_BLOCK_BYTES;
 		const size_t n_batches = (max_blocks + bps - 1) / bps;
-		constexpr int kBufs = 3;
+		const int depth = std::max(1, std::min(tfrec_amd_fifo_depth(), TFREC_AMD_FIFO_DEPTH));
+		constexpr int kBufs = TFREC_AMD_FIFO_DEPTH + 1;
 		uint8_t *host[kBufs];
 		bool pinned[kBufs];  // per buffer: each is released by the allocator it came from
 		for (int b = 0; b < kBufs; b++) {
@@ -245,11 +259,16 @@ struct device_worker {
 			const int nb = (int)std::min<size_t>(bps, max_blocks - k * bps);
 			return tfrec_amd_submit_host(ctx, host[k % kBufs], row, nb);
 		};
-		if (n_batches > 0)
-			r = submit(0);
+		size_t queued = 0;
 		for (size_t k = 0; k < n_batches && r == 0; k++) {
-			if (k + 1 < n_batches && (r = submit(k + 1)) != 0)
+			while (queued < n_batches && queued < k + (size_t)depth && r == 0)
+				r = submit(queued++);
+			if (r)
 				break;
+			if (abort && abort->load()) {
+				r = TFREC_AMD_E_STATE;
+				break;
+			}
 			std::vector<tfrec_amd_event> ev(cfg.max_events);
 			int nev = 0;
 			r = tfrec_amd_drain_events(ctx, ev.data(), (int)ev.size(), &nev);
@@ -326,10 +345,14 @@ int gpu_engine::run()
 		w.thresh = thresh;
 		w.filter = filter;
 		w.bps = bps;
+		w.flags = bits_replay ? (TFREC_AMD_F_BITS | TFREC_AMD_F_ALL_FLUSHES) : 0u;
 		w.max_blocks = max_blocks;
 	}
-	for (size_t d = 0; d < nd; d++)
+	std::atomic<bool> abort(false);
+	for (size_t d = 0; d < nd; d++) {
+		workers[d].abort = &abort;
 		workers[d].th = std::thread([&workers, d]() { workers[d].run(); });
+	}
 	int rc = 0;
 	std::vector<tfrec_amd_event> ev;
 	for (size_t k = 0; k < n_batches && rc == 0; k++) {
@@ -338,11 +361,17 @@ int gpu_engine::run()
 				rc = workers[d].rc ? workers[d].rc : TFREC_AMD_E_STATE;
 				break;
 			}
-			// per stream in time order, slots in registration order like the reference's dispatch loop (fm_demod.cpp:48-49)
-			std::sort(ev.begin(), ev.end(), [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
+			// per stream in time order, slots in registration order like the reference's dispatch loop (fm_demod.cpp:48-49).
+			// BITS chunks carry the first sample of their trigger window (a chunk has no per-bit time): a window's bits
+			// are replayed when it opens, its flush when it closes -- what store_bit prints keeps its place among the
+			// flushes of every window that does not overlap this one.
+			std::stable_sort(ev.begin(), ev.end(), [](const tfrec_amd_event &a, const tfrec_amd_event &b) {
 				if (a.stream != b.stream) return a.stream < b.stream;
 				if (a.end_sample != b.end_sample) return a.end_sample < b.end_sample;
-				return a.slot < b.slot;
+				const bool ab = a.status == TFREC_AMD_STATUS_BITS, bb = b.status == TFREC_AMD_STATUS_BITS;
+				if (ab != bb) return ab;
+				if (a.slot != b.slot) return a.slot < b.slot;
+				return ab && a.offset < b.offset;
 			});
 			for (size_t q = 0; q < ev.size(); q++)
 				if (ev[q].end_sample < stream_samples[ev[q].stream])
@@ -351,7 +380,9 @@ int gpu_engine::run()
 		if (psink)
 			psink->flush();  // the records of the whole batch in one write
 	}
-	// (after an error: drain the queues so that the workers can finish)
+	// (after an error: tell the healthy workers to stop, and empty the queues so that they can finish)
+	if (rc)
+		abort.store(true);
 	for (size_t d = 0; d < nd; d++) {
 		while (workers[d].pop(ev)) {
 		}

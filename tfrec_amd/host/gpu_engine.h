@@ -92,6 +92,11 @@ public:
 	// exec: per-telegram handler as the reference's -e (system() per record); batched: the same command started
 	// once, records on its stdin (pipe_sink); mode: the reference's -m (1 = summary at the end)
 	void set_handler(const char *exec, bool batched, int mode);
+	// BITS-mode replay (SURVEY 8b "In BITS mode call dec->store_bit(b) per bit then flush"): the context reports every bit
+	// the demodulators hand to decoder::store_bit (TFREC_AMD_F_BITS) and every flush; the decoders then run exactly as
+	// inside the reference -- including what store_bit itself prints (tfa2.cpp:294-300 "Inverted SYNC").  Default off:
+	// the byte-level replay (store_bytes + flush) moves 64 bytes per window instead of every bit.
+	void set_bits_replay(bool on) { bits_replay = on; }
 	// returns 0 on success, a TFREC_AMD_E_* code otherwise
 	int run();
 	// decoders of stream s in slot order (NULL for slots not registered)
@@ -109,6 +114,7 @@ private:
 	batch_sink *sink;  // (the decoders hold its address)
 	pipe_sink *psink;
 	int out_mode;
+	bool bits_replay;
 };
 
 #endif

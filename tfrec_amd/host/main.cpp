@@ -1,6 +1,6 @@
 // tfrec_amd/host/main.cpp -- tfrec_gpu: the reference's file-replay CLI on the GPU path.
 //
-//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d device[,device...]] [-b blocks] [-e handler | -E handler] [-m mode]
+//   tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-B] [-d device[,device...]] [-b blocks] [-e handler | -E handler] [-m mode]
 //             -L dump.iq [-L more.iq ...]
 //   tfrec_gpu [-T hexmask] -X telegrams.txt
 //
@@ -9,6 +9,8 @@
 // -e handler executed for every message, -m 1 summary at exit,
 // -L raw 8-bit IQ dump as written by "tfrec -S", -X hex telegrams for the byte-level test entry
 // (main.cpp:24-53).  Several -L files are processed as one batch, one stream each.
+// -B (not in the reference): BITS-mode replay -- every demodulated bit goes through the decoder's own store_bit
+// (gpu_engine.h), so that stdout also carries what store_bit prints ("Inverted SYNC", tfa2.cpp:294-300).
 // -E handler (not in the reference): the handler is started ONCE and receives the records of all
 // streams on stdin, "<stream> <id> <temp> <hum> <seq> <alarm> <rssi> <flags> <ts>" per line, one write per batch.
 #include <stdio.h>
@@ -63,16 +65,17 @@ int main(int argc, char **argv)
 	std::vector<int> devices;
 	std::vector<std::string> dumps;
 	const char *hexfile = NULL, *exec = NULL;
-	bool batched = false;
+	bool batched = false, bits = false;
 	int mode = 0;
 	int c;
-	while ((c = getopt(argc, argv, "T:t:WqDd:b:L:X:e:E:m:h")) != -1) {
+	while ((c = getopt(argc, argv, "T:t:WqDBd:b:L:X:e:E:m:h")) != -1) {
 		switch (c) {
 		case 'T': types = (int)strtol(optarg, NULL, 16); break;
 		case 't': thresh = atoi(optarg); break;
 		case 'W': filter = 1; break;
 		case 'q': dbg = -1; break;
 		case 'D': dbg++; break;
+		case 'B': bits = true; break;
 		case 'd':  // one ordinal or a comma-separated list: the dump files are sharded over the devices by index
 			for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ","))
 				devices.push_back(atoi(tok));
@@ -84,7 +87,7 @@ int main(int argc, char **argv)
 		case 'E': exec = optarg; batched = true; break;
 		case 'm': mode = atoi(optarg); break;
 		default:
-			fprintf(stderr, "usage: tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-d dev] [-b blocks] -L dump [-L dump ...] | -X hexfile\n");
+			fprintf(stderr, "usage: tfrec_gpu [-T hexmask] [-t thresh] [-W] [-q] [-D] [-B] [-d dev] [-b blocks] -L dump [-L dump ...] | -X hexfile\n");
 			return c == 'h' ? 0 : 1;
 		}
 	}
@@ -102,6 +105,7 @@ int main(int argc, char **argv)
 	gpu_engine e(dumps, types, thresh, filter, dbg, devices, blocks);
 	if (exec || mode)
 		e.set_handler(exec, batched, mode);
+	e.set_bits_replay(bits);
 	int rc = e.run();
 	fflush(stdout);
 	return rc ? 2 : 0;
