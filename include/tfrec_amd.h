@@ -111,6 +111,7 @@ typedef struct {
 	/* ... and so does the TFA_1 chain (no biquad stage): short-window slicer, cooperative slicer, decode + commit */
 	float tfa1_slicer_ms, tfa1_coop_slicer_ms, tfa1_decode_commit_ms;
 	float fmdev_ms;    /* FM discriminator pass of the front end (tiles near trigger windows) */
+	float whb_verify_ms; /* WHB stage 2 check: the exact decision-level recurrence, lane per stream (0: the exact stage 2 ran) */
 } tfrec_amd_timings;
 
 const char *tfrec_amd_version(void);
@@ -211,7 +212,9 @@ typedef struct {
 	uint64_t tfa1_recomputed;    /* 64-sample steps of long TFA_1 windows whose pre-computed peak detector piece did not
 				        start from the true value and were recomputed */
 	uint64_t biquad_repair_slots; /* 32-sample slots the first repair pass ran (a segment has up to 116) */
-	uint64_t reserved[2];
+	uint64_t whb_respeculated;   /* (stream, submit) pairs whose lane-parallel WHB decision levels did not reproduce the exact
+				        recurrence's decisions and were demodulated again by the exact kernel */
+	uint64_t reserved[1];
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
 /* Number of internal HIP streams the context's pipeline is laid out on: 6 = deep (default: the filter stage of submit

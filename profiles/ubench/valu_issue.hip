@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void issue_kernel(unsigned long long *t, int r
 			REP64(X)
 #undef X
 		} else if (CLS == 7) {  // SALU
-#define X(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s0) : "s"(s1));
+#define X(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s0) : "s"(s1) : "scc");
 			REP64(X)
 #undef X
 		} else if (CLS == 8) {  // v_cvt_f64_i32 (conversions: quarter rate?)

@@ -537,3 +537,49 @@ def test_event_buffer_overflow_is_reported_and_the_context_goes_on():
         ev = np.concatenate([r.drain(), r.drain()])
         for s in range(n_streams):
             check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
+
+
+@pytest.mark.parametrize("deep", ["1", "0"])
+@pytest.mark.parametrize("every", [1, 3])
+def test_whb_speculation_failures_are_redone_exactly(every, deep, monkeypatch):
+    """WHB stage 2 speculates its decision levels and whb_verify_kernel checks them against the exact recurrence; a stream
+    that fails is redone by the exact kernel from the state the submit started from, its speculative events retracted, and
+    every later submit that was speculated from the superseded state is redone too.  TFREC_AMD_WHB_FORCE_FAIL declares
+    every N-th (stream + submit) failed: the events must still be the oracle's -- with four submits in flight (a failed
+    submit's successors are already running from the wrong state), alternating submit / drain, and in both stream layouts."""
+    monkeypatch.setenv("TFREC_AMD_WHB_FORCE_FAIL", str(every))
+    monkeypatch.setenv("TFREC_AMD_DEEP", deep)
+    n_streams, n_blocks = 24, 40
+    iq = synth.gen_batch(91, 3, n_streams, n_blocks)
+    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in ((0, 6), (6, 9), (9, 20), (20, 28), (28, 33), (33, 40))]
+    for types in (0x2F, 0x20):
+        with api.Receiver(n_streams, types, 500, 0, max_blocks=11, all_flushes=True) as r:
+            evs, q = [], 0
+            for k in range(len(parts)):
+                while q < len(parts) and q - k < api.FIFO_DEPTH:
+                    r.submit(parts[q])
+                    q += 1
+                evs.append(r.drain())
+            ev = np.concatenate(evs)
+            assert not (ev["status"] == 0xFF).any()
+            assert _all_streams_equal(ev, iq, types, 500) > (10 if types == 0x2F else 2) * n_streams
+            redone = r.stats()["whb_respeculated"]
+            assert redone >= n_streams * len(parts) // every // 2, redone
+        with api.Receiver(n_streams, types, 500, 0, max_blocks=11, all_flushes=False) as r:  # default mode, one in flight
+            evs = []
+            for p in parts:
+                r.submit(p)
+                evs.append(r.drain())
+            assert _all_streams_equal(np.concatenate(evs), iq, types, 500, all_flushes=False) > n_streams
+
+
+def test_whb_speculation_is_verified_and_rarely_fails():
+    """Without forced failures: the speculative WHB stage reproduces the exact kernel's events (TFREC_AMD_WHB_EXACT=1 is the
+    wave-per-stream recurrence, exact by itself) and the verification accepts practically every stream."""
+    n_streams, n_blocks = 64, 24
+    iq = synth.gen_batch(92, 0, n_streams, n_blocks)
+    with api.Receiver(n_streams, 0x20, 500, 0, max_blocks=n_blocks, all_flushes=True) as r:
+        r.submit(iq)
+        ev = r.drain()
+        assert _all_streams_equal(ev, iq, 0x20, 500) > n_streams
+        assert r.stats()["whb_respeculated"] <= 1

@@ -52,13 +52,14 @@ class Timings(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("frontend_ms", "chains_ms", "total_ms", "windows_ms", "spec_biquad_ms",
                                          "repair_biquad_ms", "fix_biquad_ms", "slicer_ms", "coop_slicer_ms", "decode_ms",
                                          "commit_ms", "whb_biquad_ms", "whb_demod_ms", "whb_decode_ms", "whb_commit_ms",
-                                         "tfa1_slicer_ms", "tfa1_coop_slicer_ms", "tfa1_decode_commit_ms", "fmdev_ms")]
+                                         "tfa1_slicer_ms", "tfa1_coop_slicer_ms", "tfa1_decode_commit_ms", "fmdev_ms",
+                                         "whb_verify_ms")]
 
 
 class Stats(C.Structure):
     _fields_ = [("biquad_segments", C.c_uint64), ("biquad_unconverged", C.c_uint64), ("biquad_serial", C.c_uint64),
                 ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("biquad_repair_slots", C.c_uint64),
-                ("reserved", C.c_uint64 * 2)]
+                ("whb_respeculated", C.c_uint64), ("reserved", C.c_uint64 * 1)]
 
 
 class FmStats(C.Structure):
@@ -271,7 +272,7 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:6]}
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:7]}
 
 
 def fm_dev_probe(records: np.ndarray, device: int = 0, cross: bool = False):

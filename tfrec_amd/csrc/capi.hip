@@ -93,6 +93,14 @@ struct tfrec_amd_ctx {
 	WinTables win[kSets] = {};
 	void *win_block[kSets] = {};
 	int32_t *d_tcarry = nullptr;                 // WinTables::timeout_carry
+	WhbExact *d_whbx = nullptr;                  // WinTables::whbx
+	int *d_whbcarry = nullptr;                   // PipeCtl::whb_carry
+	uint32_t *d_whbgen = nullptr;                // WinTables::whbgen
+	ChainState *d_whbX = nullptr;                // WinTables::whbX
+	int whb_force_fail = 0;                      // TFREC_AMD_WHB_FORCE_FAIL (tests)
+	int submit_seq = 0;
+	hipStream_t vx = nullptr;                    // whb_verify_kernel: an alias of cp (deep layout) or of aux
+	hipEvent_t ev_aux[kSets] = {};               // whb_demod_kernel of the set's submit done
 	FskState *d_fsk = nullptr;  // auto-threshold mode only
 	int wmax = 0;
 	uint8_t *d_tail[kSets] = {};
@@ -289,6 +297,13 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 				(void)hipEventDestroy(e);
 	}
 	(void)hipFree(c->d_tcarry);
+	(void)hipFree(c->d_whbx);
+	(void)hipFree(c->d_whbcarry);
+	(void)hipFree(c->d_whbgen);
+	(void)hipFree(c->d_whbX);
+	for (auto &e : c->ev_aux)
+		if (e)
+			(void)hipEventDestroy(e);
 	if (c->deep && c->k2)
 		(void)hipStreamDestroy(c->k2);
 	if (c->deep && c->kw)
@@ -472,6 +487,19 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		ALLOC(c->d_tcarry, chains * 4);
 		if (rc == TFREC_AMD_OK && hipMemset(c->d_tcarry, 0, chains * 4) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
+		if (whb) {  // iir_avg starts from zero like every iir2 (dsp_stuff.cpp:28-34)
+			ALLOC(c->d_whbx, n * sizeof(WhbExact));
+			ALLOC(c->d_whbcarry, n * sizeof(int));
+			ALLOC(c->d_whbgen, n * sizeof(uint32_t));
+			ALLOC(c->d_whbX, n * sizeof(ChainState));
+			if (rc == TFREC_AMD_OK && hipMemset(c->d_whbgen, 0, n * sizeof(uint32_t)) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+			if (const char *ff = getenv("TFREC_AMD_WHB_FORCE_FAIL"))
+				c->whb_force_fail = atoi(ff);
+			if (rc == TFREC_AMD_OK && (hipMemset(c->d_whbx, 0, n * sizeof(WhbExact)) != hipSuccess ||
+						   hipMemset(c->d_whbcarry, 0, n * sizeof(int)) != hipSuccess))
+				rc = TFREC_AMD_E_HIP;
+		}
 		for (int set = 0; set < kSets; set++) {
 		WinTables &T = c->win[set];
 		T.cap = (int32_t)(m_max / 356 + 2);  // windows of one chain are > W-1 >= 355 samples apart
@@ -499,6 +527,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
 		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4);
 		const size_t o_cand = carve(n * (size_t)T.slots * 4), o_mark = carve(n * (size_t)T.slots * sizeof(MarkPiece));
+		T.whbrec_stride = (int32_t)(m_max / 64 + (size_t)T.cap + 2);
+		const size_t o_wrec = carve(whb ? n * (size_t)T.whbrec_stride * 8 : 0), o_wfail = carve(whb ? n * 4 : 0);
+		const size_t o_wsnap = carve(whb ? n * sizeof(ChainState) : 0), o_wx0 = carve(whb ? n * sizeof(WhbExact) : 0);
+		const size_t o_wseen = carve(whb ? n * 4 : 0);
 		ALLOC(c->win_block[set], off);
 		if (rc == TFREC_AMD_OK) {
 			uint8_t *b = (uint8_t *)c->win_block[set];
@@ -525,6 +557,15 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.segfix2 = (int32_t *)(b + o_sfix2);
 			T.cand = (uint32_t *)(b + o_cand);
 			T.mark = (MarkPiece *)(b + o_mark);
+			T.whbrec = (unsigned long long *)(b + o_wrec);
+			T.whbfail = (int32_t *)(b + o_wfail);
+			T.whbsnap = (ChainState *)(b + o_wsnap);
+			T.whbx0 = (WhbExact *)(b + o_wx0);
+			T.whbseen = (uint32_t *)(b + o_wseen);
+			T.whbgen = c->d_whbgen;
+			T.whbX = c->d_whbX;
+			T.whb_force_fail = c->whb_force_fail;
+			T.whbx = c->d_whbx;
 			T.timeout_carry = c->d_tcarry;
 			T.prevdec = c->d_prevdec[set];
 			if (hipMemset(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
@@ -608,10 +649,19 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		c->fmdev_k2 = getenv("TFREC_AMD_FMDEV_K2") ? atoi(getenv("TFREC_AMD_FMDEV_K2")) != 0 : has_whb;
 		c->k2 = c->cs;
 		c->kw = c->aux;
+		c->vx = c->aux;
 		if (c->deep && rc == TFREC_AMD_OK &&
 		    (hipStreamCreateWithFlags(&c->k2, hipStreamNonBlocking) != hipSuccess ||
 		     hipStreamCreateWithFlags(&c->kw, hipStreamNonBlocking) != hipSuccess))
 			rc = TFREC_AMD_E_HIP;
+		// whb_verify_kernel runs on the copy stream, ahead of its submit's device-to-host copies (they wait for it anyway).
+		// A stream of its own would be the FIFTH of normal priority in the process (k2, kw, cp and the caller's): it shared a
+		// hardware queue with kw, and the 6 ms verification of submit k held up the WHB biquads of submit k + 2.
+		if (c->deep)
+			c->vx = c->cp;
+		for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++)
+			if (hipEventCreateWithFlags(&c->ev_aux[k], hipEventDisableTiming) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
 	}
 	if (rc == TFREC_AMD_OK && (cfg->flags & TFREC_AMD_F_TIMING)) {
 		for (int k = 0; k < kSets; k++) {
@@ -710,6 +760,9 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.cs = c->cs;
 		P.aux = c->aux;
 		P.t1 = c->t1;
+		P.vx = c->vx;
+		P.ev_aux = c->ev_aux[set];
+		P.whb_carry = c->d_whbcarry;
 		P.ev_win = c->ev_pipe[set][0];
 		P.ev_fork = c->ev_pipe[set][1];
 		P.ev_k2 = c->ev_pipe[set][2];
@@ -721,6 +774,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.fm_flag_eps = c->fm_flag_eps;
 		P.fmdev_out = c->d_fmdev[set];
 		P.prevdec = c->d_prevdec[set];
+		c->win[set].whb_submit_seq = c->submit_seq++;
 		HIPCHK(launch_pipeline(P, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set], c->dec_stride,
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
 				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
@@ -814,7 +868,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->aux, c->t1, c->cp })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;
@@ -834,7 +888,7 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 	HIPCHK(hipSetDevice(c->cfg.device));
 	HIPCHK(hipEventSynchronize(c->copied[c->head]));  // the oldest submit not yet drained
 	const EventBuf eb = *c->h_eb[c->head];
-	*n = (int)std::min(eb.count, eb.capacity);
+	*n = (int)(std::min(eb.count, eb.capacity) - std::min(eb.dead, std::min(eb.count, eb.capacity)));  // (retracted events are not reported)
 	return eb.count > eb.capacity ? TFREC_AMD_E_OVERFLOW : TFREC_AMD_OK;
 }
 
@@ -862,6 +916,13 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 		HIPCHK(hipMemcpy(tmp + c->copied_n[set], c->d_events[set] + c->copied_n[set],
 				 (size_t)(have - c->copied_n[set]) * sizeof(tfrec_amd_event), hipMemcpyDeviceToHost));
 	c->copy_guess = std::max<uint32_t>(c->copy_guess_min, 2 * have);
+	uint32_t live = have;
+	if (eb.dead) {  // a WHB stream's speculative events that the exact kernel replaced (rare): never reported
+		live = 0;
+		for (uint32_t i = 0; i < have; i++)
+			if (tmp[i].status != kStatusDead)
+				tmp[live++] = tmp[i];
+	}
 	c->head = (c->head + 1) % kSets;
 	c->inflight--;
 	c->last_drained = set;
@@ -892,21 +953,21 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	};
 	const uint32_t ns = (uint32_t)c->cfg.n_streams;
 	std::vector<uint32_t> &idx = c->sort_idx, &start = c->sort_start;
-	idx.resize(have);
+	idx.resize(live);
 	start.assign(ns + 1, 0u);
-	for (uint32_t i = 0; i < have; i++)
+	for (uint32_t i = 0; i < live; i++)
 		start[std::min(tmp[i].stream, ns - 1) + 1]++;
 	for (uint32_t s = 0; s < ns; s++)
 		start[s + 1] += start[s];
 	{
 		std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-		for (uint32_t i = 0; i < have; i++)
+		for (uint32_t i = 0; i < live; i++)
 			idx[fill[std::min(tmp[i].stream, ns - 1)]++] = i;
 	}
 	for (uint32_t s = 0; s < ns; s++)
 		std::sort(idx.begin() + start[s], idx.begin() + start[s + 1],
 			  [&](uint32_t x, uint32_t y) { return before(tmp[x], tmp[y]); });
-	uint32_t ncopy = have;
+	uint32_t ncopy = live;
 	if (ncopy > (uint32_t)cap) {
 		ncopy = (uint32_t)cap;
 		overflow = true;
@@ -1071,6 +1132,7 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	out->coop_slicer_ms = out->decode_ms = out->commit_ms = 0;
 	out->whb_biquad_ms = out->whb_demod_ms = out->whb_decode_ms = out->whb_commit_ms = 0;
 	out->tfa1_slicer_ms = out->tfa1_coop_slicer_ms = out->tfa1_decode_commit_ms = 0;
+	out->whb_verify_ms = 0;
 	if (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) {
 		HIPCHK(hipEventElapsedTime(&out->chains_ms, ev[1], ev[2]));
 		HIPCHK(hipEventElapsedTime(&out->total_ms, ev[0], ev[2]));
@@ -1108,6 +1170,9 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	if (has[1]) {
 		HIPCHK(hipEventElapsedTime(&out->whb_biquad_ms, tev[9], tev[12]));
 		HIPCHK(hipEventElapsedTime(&out->whb_demod_ms, tev[22], tev[13]));
+		if (hipEventQuery(tev[27]) == hipSuccess && hipEventElapsedTime(&out->whb_verify_ms, tev[26], tev[27]) != hipSuccess)
+			out->whb_verify_ms = 0;
+		(void)hipGetLastError();
 		// whb_decode_ms / whb_commit_ms stay 0: those stages run in the tail of whb_demod_kernel
 	}
 	return TFREC_AMD_OK;

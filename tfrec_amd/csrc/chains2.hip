@@ -1883,7 +1883,8 @@ __device__ __forceinline__ void whb_commit_stream(int s, int n_streams, int n_bl
 		if (rr->closed) {  // whb.cpp:693-697
 			const long long rssi =
 				(long long)((unsigned long long)(uint32_t)rr->rssi_i | ((unsigned long long)(uint32_t)rr->offset << 32));
-			flush<2>(e, d, rssi, 0, last);
+			// (the event's index: should the stream's speculation turn out wrong, the exact kernel retracts the event)
+			T.result[(size_t)c * T.cap + j].first_cand_g = flush<2>(e, d, rssi, 0, last);
 		}
 	}
 	{
@@ -1961,11 +1962,103 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)  // wave-unif
 	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+// lane n <- lane n - d of its row of 16 (zero for the first d lanes of a row): DPP row_shr with bound_ctrl
+template <int D>
+__device__ __forceinline__ double row_shr_f64(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + D, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + D, 0xf, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+
+// The decision-level average over one 64-sample step, all samples at once (EXACT = false).  y(k) = a1 y(k-1) + a2 y(k-2)
+// + x(k) in state form s(k) = M s(k-1) + (x(k), 0), M = [[a1, a2], [1, 0]]: a zero-state scan inside every row of 16
+// lanes (four DPP levels with M, M^2, M^4, M^8), the rows' end states E_q by readlane, and the carry-in of the step's
+// start state (y1, y2) and of the rows before as per-lane constant rows of powers of M:
+//     y(k) = u(k) + R(k+1) . (y1, y2) + sum_{q < k/16} R(k - 16 q - 15) . E_q,     R(n) = first row of M^n.
+// ~60 vector instructions per step instead of the 6 x 64 of the serial recurrence -- but in another order of
+// operations, so not the reference's bits: the result only SPECULATES the decisions "dev < (int)avg";
+// whb_verify_kernel checks them against the exact recurrence.
+struct WhbScan {
+	double m2[4], m4[4], m8[4];   // M^2, M^4, M^8 (m11, m12, m21, m22), wave-uniform
+	double cy1, cy2;              // R(k + 1)
+	double ce[3][2];              // R(k - 16 q - 15), zero where q >= k / 16
+	double a1;
+};
+__device__ __forceinline__ void whb_scan_init(WhbScan &w, double a1, double a2, int ln)
+{
+	w.a1 = a1;
+	w.cy1 = w.cy2 = 0.0;
+#pragma unroll
+	for (int q = 0; q < 3; q++)
+		w.ce[q][0] = w.ce[q][1] = 0.0;
+	// g(n): impulse response of 1 / (1 - a1 z^-1 - a2 z^-2); M^n = [[g(n), a2 g(n-1)], [g(n-1), a2 g(n-2)]]
+	double gm2 = 0.0, gm1 = 0.0, g = 1.0;  // g(n-2), g(n-1), g(n) at n = 0 (g(-1) = 0; g(-2) only enters as a2 g(-2) = 1 at n = 1)
+	for (int n = 0; n <= 64; n++) {
+		if (n == 2 || n == 4 || n == 8) {
+			double *m = n == 2 ? w.m2 : (n == 4 ? w.m4 : w.m8);
+			m[0] = g;
+			m[1] = a2 * gm1;
+			m[2] = gm1;
+			m[3] = a2 * gm2;
+		}
+		if (n == ln + 1) {
+			w.cy1 = g;
+			w.cy2 = a2 * gm1;
+		}
+#pragma unroll
+		for (int q = 0; q < 3; q++)
+			if (n >= 1 && n == ln - 16 * q - 15) {
+				w.ce[q][0] = g;
+				w.ce[q][1] = a2 * gm1;
+			}
+		const double gn = a1 * g + a2 * gm1;
+		gm2 = gm1;
+		gm1 = g;
+		g = gn;
+	}
+}
+// x: the lane's filter input b0 * (d(k) + 2 d(k-1) + d(k-2)); (y1, y2): the two outputs before the step
+__device__ __forceinline__ double whb_scan_step(const WhbScan &w, double x, double y1, double y2)
+{
+	const double xs = row_shr_f64<1>(x);
+	double u = __builtin_fma(w.a1, xs, x), v = xs;
+	{
+		const double us = row_shr_f64<2>(u), vs = row_shr_f64<2>(v);
+		const double un = __builtin_fma(w.m2[0], us, __builtin_fma(w.m2[1], vs, u));
+		v = __builtin_fma(w.m2[2], us, __builtin_fma(w.m2[3], vs, v));
+		u = un;
+	}
+	{
+		const double us = row_shr_f64<4>(u), vs = row_shr_f64<4>(v);
+		const double un = __builtin_fma(w.m4[0], us, __builtin_fma(w.m4[1], vs, u));
+		v = __builtin_fma(w.m4[2], us, __builtin_fma(w.m4[3], vs, v));
+		u = un;
+	}
+	{
+		const double us = row_shr_f64<8>(u), vs = row_shr_f64<8>(v);
+		const double un = __builtin_fma(w.m8[0], us, __builtin_fma(w.m8[1], vs, u));
+		v = __builtin_fma(w.m8[2], us, __builtin_fma(w.m8[3], vs, v));
+		u = un;
+	}
+	double y = __builtin_fma(w.cy1, y1, __builtin_fma(w.cy2, y2, u));
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const double eu = readlane_f64(u, 16 * q + 15), ev = readlane_f64(v, 16 * q + 15);
+		y = __builtin_fma(w.ce[q][0], eu, __builtin_fma(w.ce[q][1], ev, y));
+	}
+	return y;
+}
+
+// REDO (EXACT only): launched behind whb_verify_kernel over all streams, does the submit of those it failed again.
+template <bool EXACT, bool REDO>
 __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						       const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 						       long long sample_base, ChainLaunch L, int a, WinTables T,
 						       tfrec_amd_event *__restrict__ events, EventBuf *__restrict__ eb, uint32_t flags)
 {
+	constexpr bool redo = REDO;
+	static_assert(EXACT || !REDO, "only the exact kernel redoes a submit");
 	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 64 B, used by the decoder tail
 #ifdef TFREC_AMD_WHB_PRIO
 	__builtin_amdgcn_s_setprio(TFREC_AMD_WHB_PRIO);
@@ -1976,7 +2069,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	// it) and run at half speed, and the kernel ends with its slowest stream: a third of the streams ran doubled up,
 	// the slowest took 2.2x the average (profiles/ubench/whb_cycles.py span); with the claim 8.7 -> 6.7 ms in the batch.
 #ifndef TFREC_AMD_WHB_THIN
-	asm volatile("" ::: "v255", "a7");
+	if (EXACT && !REDO)  // (the redo launch: a thousand workgroups that return at once must not wait for half a SIMD each)
+		asm volatile("" ::: "v255", "a7");
 #endif
 	constexpr int kStep = 64;  // samples per iteration: one per lane
 	const int ln = threadIdx.x;
@@ -1985,6 +2079,46 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
 	const int count = T.count[c];
+	constexpr int kStateChunks = (int)(sizeof(ChainState) / 16);
+	static_assert(kStateChunks <= 64, "a wave copies a ChainState in one go");
+	if (!EXACT) {
+		// what a redo of this submit would start from (whb_verify_kernel decides): the generation first, then the state
+		const uint32_t gen = __atomic_load_n(&T.whbgen[s], __ATOMIC_RELAXED);
+		__threadfence();
+		if (ln < kStateChunks)
+			reinterpret_cast<uint4 *>(&T.whbsnap[s])[ln] = reinterpret_cast<const uint4 *>(&L.states[a][s])[ln];
+		if (ln == 0)
+			T.whbseen[s] = gen;
+	} else if (redo) {
+		// ---- the stream's speculative pass over this submit did not reproduce the exact recurrence (or started from a state
+		// a redo has replaced since): retract its events, restore the state it should have started from, and run the
+		// submit again with the exact recurrence
+		if (!T.whbfail[s])
+			return;
+		for (int j = ln; j < count; j += 64) {
+			const int idx = T.result[(size_t)c * T.cap + j].first_cand_g;
+			if (T.result[(size_t)c * T.cap + j].closed && idx >= 0 && (uint32_t)idx < eb->capacity) {
+				events[idx].status = (uint8_t)kStatusDead;
+				atomicAdd(&eb->dead, 1u);
+			}
+		}
+		const bool stale = T.whbseen[s] != T.whbgen[s];
+		const ChainState *from = stale ? &T.whbX[s] : &T.whbsnap[s];
+		if (ln < kStateChunks)
+			reinterpret_cast<uint4 *>(&L.states[a][s])[ln] = reinterpret_cast<const uint4 *>(from)[ln];
+		__threadfence();
+		__syncthreads();
+		if (!stale && ln == 0) {  // the filter's exact state at the submit's start (the snapshot holds the speculated one)
+			const WhbExact x = T.whbx0[s];
+			ChainState &st0 = L.states[a][s];
+			st0.iir_avg.yn = x.y1;
+			st0.iir_avg.yn1 = x.y2;
+			st0.iir_avg.dn1 = 0.5 * (double)x.fd1;
+			st0.iir_avg.dn2 = 0.5 * (double)x.fd2;
+		}
+		__threadfence();
+		__syncthreads();
+	}
 #ifdef TFREC_AMD_PROFILE_WHB
 	long long pf_rec = 0, pf_steps = 0, pf_usteps = 0, pf_t0 = __builtin_readcyclecounter();
 	long long pf_top = 0, pf_walk = 0, pf_tail = 0, pf_mark = 0;
@@ -2024,6 +2158,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
 		int sc = st.sr_cnt, bc = st.byte_cnt;
 		const bool cont = T.cont[c] != 0;
+		// EXACT = false: the filter's steps are evaluated lane-parallel (whb_scan_step) and their decisions recorded for
+		// whb_verify_kernel: one word per step in which the filter ran, numbered through the submit
+		WhbScan scan;
+		if (!EXACT)
+			whb_scan_init(scan, a1, a2, ln);
+		unsigned long long *const recrow = T.whbrec + (size_t)s * T.whbrec_stride;
+		int vstep = 0;
 
 		// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
 		auto feed = [&](uint32_t e, int len) -> bool {
@@ -2063,6 +2204,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				step0 = 0;
 				since = 0;
 			}
+			const int vbase = vstep;
+			int lock_pos = -1, avg_frozen = 0;  // (window-relative sample at which the decoder locked in this window)
+			// a candidate test against the FROZEN average that would come out differently with the average one higher or
+			// lower: only then does it matter that (int) of the speculated average may be the exact one's neighbour
+			bool amb = false;
 			if (ln == 0) {
 				WhbStart ws;
 				ws.sr = __brev(srr);
@@ -2120,37 +2266,57 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					pf_usteps++;
 					pf_top += pf_a - pf_mark;
 #endif
-					// ---- (3) the serial feedback recurrence, 64 samples (a window's last, partial step runs it over whatever
-					// follows the window: finite numbers, never looked at): whb_chain_asm.h.  The feed-forward pairs as four
-					// row-replicated sets: lane 16r + i holds sample 16j + i of set j.
-					// (two v_permlane16/32_swap levels per dword: no LDS round trip in the step -- the CU's LDS pipe belongs to
-					// the front end's workgroups, and a lone wave waiting behind them was the slowest stream of the batch)
-					double inp[4], inb[4];
-					rows_replicate(ffp, inp);
-					rows_replicate(t2, inb);
-					double z0, z1, z2, z3, tt, tq, ya = 0.0, yb = 0.0, yc = y2, yd = y1;
-					asm volatile(TFREC_WHB_CHAIN_ASM
-						     : [Y0] "+v"(ya), [Y1] "+v"(yb), [Y2] "+v"(yc), [Y3] "+v"(yd), [Z0] "=&v"(z0), [Z1] "=&v"(z1),
-						       [Z2] "=&v"(z2), [Z3] "=&v"(z3), [T] "=&v"(tt), [Q] "=&v"(tq)
-						     : [a1] "s"(a1), [a2] "s"(a2), [ONE] "v"(1.0), [P0] "v"(inp[0]), [B0] "v"(inb[0]), [P1] "v"(inp[1]),
-						       [B1] "v"(inb[1]), [P2] "v"(inp[2]), [B2] "v"(inb[2]), [P3] "v"(inp[3]), [B3] "v"(inb[3]));
-					const int zq = ln & 3;
-					ym = zq == 0 ? z0 : (zq == 1 ? z1 : (zq == 2 ? z2 : z3));  // y(ln)
-					if (nv == kStep) {
-						y1 = yd;
-						y2 = yc;
-					} else {  // the filter stops with the window's last sample
+					if (EXACT) {
+						// ---- (3) the serial feedback recurrence, 64 samples (a window's last, partial step runs it over whatever
+						// follows the window: finite numbers, never looked at): whb_chain_asm.h.  The feed-forward pairs as four
+						// row-replicated sets: lane 16r + i holds sample 16j + i of set j.
+						// (two v_permlane16/32_swap levels per dword: no LDS round trip in the step -- the CU's LDS pipe belongs to
+						// the front end's workgroups, and a lone wave waiting behind them was the slowest stream of the batch)
+						double inp[4], inb[4];
+						rows_replicate(ffp, inp);
+						rows_replicate(t2, inb);
+						double z0, z1, z2, z3, tt, tq, ya = 0.0, yb = 0.0, yc = y2, yd = y1;
+						asm volatile(TFREC_WHB_CHAIN_ASM
+							     : [Y0] "+v"(ya), [Y1] "+v"(yb), [Y2] "+v"(yc), [Y3] "+v"(yd), [Z0] "=&v"(z0), [Z1] "=&v"(z1),
+							       [Z2] "=&v"(z2), [Z3] "=&v"(z3), [T] "=&v"(tt), [Q] "=&v"(tq)
+							     : [a1] "s"(a1), [a2] "s"(a2), [ONE] "v"(1.0), [P0] "v"(inp[0]), [B0] "v"(inb[0]), [P1] "v"(inp[1]),
+							       [B1] "v"(inb[1]), [P2] "v"(inp[2]), [B2] "v"(inb[2]), [P3] "v"(inp[3]), [B3] "v"(inb[3]));
+						const int zq = ln & 3;
+						ym = zq == 0 ? z0 : (zq == 1 ? z1 : (zq == 2 ? z2 : z3));  // y(ln)
+						if (nv == kStep) {
+							y1 = yd;
+							y2 = yc;
+						} else {  // the filter stops with the window's last sample
+							y1 = readlane_f64(ym, nv - 1);
+							y2 = nv > 1 ? readlane_f64(ym, nv > 1 ? nv - 2 : 0) : y1_in;
+						}
+#ifdef TFREC_AMD_PROFILE_WHB
+							pf_mark = __builtin_readcyclecounter();
+							pf_rec += pf_mark - pf_a;
+#endif
+					} else {
+						// ---- (3') all 64 samples at once (whb_scan_step): x = b0 d(k) + b1 d(k-1) + b2 d(k-2) with b1 = 2 b0, b2 = b0
+						const double x = ffp + t2;
+						ym = whb_scan_step(scan, x, y1, y2);
 						y1 = readlane_f64(ym, nv - 1);
 						y2 = nv > 1 ? readlane_f64(ym, nv > 1 ? nv - 2 : 0) : y1_in;
-					}
 #ifdef TFREC_AMD_PROFILE_WHB
-					pf_mark = __builtin_readcyclecounter();
-					pf_rec += pf_mark - pf_a;
+						pf_mark = __builtin_readcyclecounter();
+						pf_rec += pf_mark - pf_a;
 #endif
+					}
 					// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
-					mask = __ballot(ln < nv && dev < (int)ym && rise);
+					const unsigned long long below = __ballot(ln < nv && dev < (int)ym);
+					if (!EXACT) {
+						if (ln == 0)
+							recrow[vstep] = below;
+						vstep++;
+					}
+					mask = below & __ballot(rise);
 				} else {
 					mask = __ballot(ln < nv && dev < avg_of && rise);
+					if (!EXACT)
+						amb = amb || __ballot(ln < nv && rise && (uint32_t)(avg_of - dev) < 2u) != 0ull;
 				}
 				// ---- (4) accepted candidates
 				int locked_at = -1;
@@ -2194,8 +2360,12 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 							fd2 = k > 0 ? dkm1 : fd1;
 							fd1 = dk;
 							avg_of = (int)yk;
+							lock_pos = kStep * i + k;
+							avg_frozen = avg_of;
 							// the rest of the step's candidates against the frozen avg_of
 							mask = __ballot(ln < nv && ln > k && dev < avg_of && rise);
+							if (!EXACT)
+								amb = amb || __ballot(ln < nv && ln > k && rise && (uint32_t)(avg_of - dev) < 2u) != 0ull;
 						}
 					}
 				}
@@ -2272,7 +2442,14 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			res.offset = (int32_t)(uint32_t)((unsigned long long)rssi_out >> 32);
 			res.lbi_out = 0;
 			res.first_cand_g = -1;
-			res.bitcnt = res.dmin = res.dmax = res.last_bit = res.mark_lvl = 0;
+			// for whb_verify_kernel: the filter steps of this window (their records start at mark_lvl), where the decoder
+			// locked (window-relative sample, -1: it did not), the average it froze there, and (last_bit) whether a candidate
+			// test of this window would change with that average off by one
+			res.bitcnt = vstep - vbase;
+			res.dmax = lock_pos;
+			res.dmin = avg_frozen;
+			res.mark_lvl = vbase;
+			res.last_bit = amb ? 1 : 0;
 			res.resume = -1;
 			if (ln == 0)
 				T.result[(size_t)c * T.cap + j] = res;
@@ -2339,8 +2516,241 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	__syncthreads();
 	if (ln == 0)
 		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_wave);
+	if (EXACT && redo) {  // the state later submits (speculated ones that started too early included) are redone from
+		__threadfence();
+		__syncthreads();
+		if (ln < kStateChunks)
+			reinterpret_cast<uint4 *>(&T.whbX[s])[ln] = reinterpret_cast<const uint4 *>(&L.states[a][s])[ln];
+		if (ln == 0) {
+			const ChainState &st1 = L.states[a][s];
+			WhbExact x;
+			x.y1 = st1.iir_avg.yn;
+			x.y2 = st1.iir_avg.yn1;
+			x.fd1 = (int)(2.0 * st1.iir_avg.dn1);
+			x.fd2 = (int)(2.0 * st1.iir_avg.dn2);
+			x.pad_[0] = x.pad_[1] = 0;
+			T.whbx[s] = x;
+			T.whbfail[s] = 0;
+			__threadfence();
+			atomicAdd(&T.whbgen[s], 1u);
+			atomicAdd(&T.stats[6], 1ull);
+		}
+	}
 }
 
+
+// ------------------------------------------------------------------------------------------------ K4v WHB verify
+// whb_demod_kernel<false> takes its decisions "dev < (int)avg" (whb.cpp:662) from a lane-parallel evaluation of the
+// decision-level average -- the same filter in another order of operations, ~5e-3 away from the reference's doubles
+// (both accumulate their own rounding errors over the filter's 7500-sample memory), which can only matter where the
+// average lies that close to dev + 1.  Here the reference's own recurrence (iir2::step in its normative association,
+// the hand-scheduled chain of whb_chain_asm.h) runs over exactly the samples the demodulator ran the filter on, and
+// every recorded decision is compared with it: FOUR STREAMS PER WAVE, one per row of 16 lanes.  The chain is serial
+// per stream and costs a wave ~35 cycles per sample whatever its lanes hold (6 fp64 instructions, DPP-broadcast inputs):
+// executed for ONE stream per wave, as the exact demodulator kernel does, it is a third of the batch's vector
+// instructions; a row of 16 lanes is all the broadcast needs.  (A lane per stream looked cheaper still and is not: the
+// conversion "(int)" alone costs a lone wave 38 cycles per instruction, scattered 16-byte accesses of 64 rows ~60 each --
+// profiles/ubench/verify_chain.hip; here both are paid once per 16 samples.)
+// The code below is written per lane; the lanes of a row hold the same stream, window and step throughout, so every
+// branch is uniform per row.  Where the decoder locked, the average was frozen as an integer (whb.cpp:653-654): (int) of
+// the speculated double is the exact one's neighbour once in ~200 locks; that is accepted iff no candidate test of the
+// window could tell the two apart (WinResult::last_bit, tracked by the demodulator kernel).
+// All equal (the rule): what whb_demod_kernel<false> emitted is the reference's result, and the exact filter state is
+// carried on in T.whbx.  Otherwise T.whbfail[s] is set: the stream's submit is redone by the exact kernel.
+struct WhbFilterRange {
+	const int32_t *wp;  // the window's stage-1 outputs
+	int total;          // the filter ran on samples [0, total) of the window
+	int vbase;          // its first step's record
+	int nf;             // filter steps (< 0: no more windows, 0: the window began locked)
+	int lock, avgf, wflags;
+};
+__device__ __forceinline__ WhbFilterRange whb_filter_range(const WinTables &T, int c, int jj, int count, int M,
+							   const int32_t *dvrow)
+{
+	WhbFilterRange d;
+	d.wp = dvrow;
+	d.total = d.vbase = d.avgf = d.wflags = 0;
+	d.lock = -1;
+	d.nf = -1;
+	if (jj < count) {
+		const WinResult r = T.result[(size_t)c * T.cap + jj];
+		const int og = T.open[(size_t)c * T.cap + jj];
+		const int close = T.close[(size_t)c * T.cap + jj];
+		const int n = (close < M ? close : M - 1) - og + 1;
+		d.nf = r.bitcnt;
+		d.lock = r.dmax;
+		d.avgf = r.dmin;
+		d.vbase = r.mark_lvl;
+		d.wflags = (r.last_bit ? 1 : 0) | (r.closed ? 2 : 0);
+		d.total = d.lock >= 0 ? d.lock + 1 : (n < 64 * d.nf ? n : 64 * d.nf);
+		d.wp = dvrow + (size_t)win_slot0(og, jj) * 32;
+	}
+	return d;
+}
+
+template <int N>
+__device__ __forceinline__ int row_ror_i32(int v)  // lane i of a row <- lane (i - N) & 15 of the same row
+{
+	return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, true);
+}
+// the value of lane `src` (0..15, the same for all lanes of a row) of the own row
+__device__ __forceinline__ int row_pick_i32(int v, int src)
+{
+	return __builtin_amdgcn_ds_bpermute(4 * (((int)threadIdx.x & 48) + src), v);
+}
+__device__ __forceinline__ double row_pick_f64(double v, int src)
+{
+	return __hiloint2double(row_pick_i32(__double2hiint(v), src), row_pick_i32(__double2loint(v), src));
+}
+
+__global__ __launch_bounds__(64) void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
+							ChainLaunch L, int a, WinTables T, int *__restrict__ carry_io)
+{
+	__builtin_amdgcn_s_setprio(1);
+	const int M = n_blocks * kBlockDec;
+	const int ln = threadIdx.x, row = ln >> 4, li = ln & 15;
+	const int s = blockIdx.x * 4 + row;
+	const bool active = s < n_streams;
+	const int sc_ = active ? s : 0;
+	const int c = a * n_streams + sc_;
+	const ChainParams &p = L.params[a];
+	const double a1 = p.iir_avg.a1, a2 = p.iir_avg.a2, bh = 0.5 * p.iir_avg.b0;
+	const int32_t *dvrow = dev32 + (size_t)sc_ * T.slots * 32;
+	const unsigned long long *recrow = T.whbrec + (size_t)sc_ * T.whbrec_stride;
+	const int count = active ? T.count[c] : 0;
+	WhbExact st = T.whbx[sc_];
+	double y1 = st.y1, y2 = st.y2;
+	int fd1 = st.fd1, fd2 = st.fd2;
+	int carry = carry_io[sc_];  // exact minus speculated frozen average of a window still open and locked (0, +1, -1)
+	bool bad = false, done = !active;
+	// the NEXT window's range is fetched while this one is filtered
+	WhbFilterRange nxt = whb_filter_range(T, c, 0, count, M, dvrow), cur = nxt;
+	int j = -1, i = 0, nsteps = 0;
+	bool have_a = false;  // dA already holds the first step of the window about to start
+	int dA[4] = { 0, 0, 0, 0 }, dB[4] = { 0, 0, 0, 0 };  // the lane's samples 16 q + li of this step / the next
+	auto load4 = [&](int (&buf)[4], const int32_t *src) {
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			buf[q] = src[16 * q + li];
+	};
+	while (true) {
+		while (!done && i >= nsteps) {  // the row's next window in which the filter ran
+			cur = nxt;
+			j++;
+			if (cur.nf < 0) {
+				done = true;
+				break;
+			}
+			nxt = whb_filter_range(T, c, j + 1, count, M, dvrow);
+			i = 0;
+			nsteps = 0;
+			if (cur.nf == 0) {  // the window began locked (it continues one of the previous submit): no filter step
+				bad = bad || (carry != 0 && (cur.wflags & 1));
+				if (cur.wflags & 2)
+					carry = 0;
+				have_a = false;
+				continue;
+			}
+			nsteps = (cur.total + 63) >> 6;
+			if (!have_a)
+				load4(dA, cur.wp);
+			have_a = false;
+		}
+		if (__ballot(!done) == 0ull)
+			break;
+		if (!done) {
+			if (i + 1 < nsteps) {
+				load4(dB, cur.wp + 64 * (i + 1));
+			} else if (nxt.nf > 0) {  // the window's last step: the next window's first is fetched meanwhile
+				load4(dB, nxt.wp);
+				have_a = true;
+			}
+			const int nv = cur.total - 64 * i < 64 ? cur.total - 64 * i : 64;
+			// ---- feed-forward half of iir2::step for the lane's four samples (iir_step_t, dsp_dev.h): sample 16 q + li has
+			// its predecessors in lanes li - 1, li - 2 of set q, or in the last lanes of set q - 1 (the filter's own input
+			// history fd1, fd2 before the step's first sample)
+			double P[4], B2[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int r1 = row_ror_i32<1>(dA[q]), r2 = row_ror_i32<2>(dA[q]);
+				const int e1 = q == 0 ? fd1 : row_ror_i32<1>(dA[q > 0 ? q - 1 : 0]);  // lane 15 of the set before, in lane 0
+				const int e2 = q == 0 ? (li == 0 ? fd2 : fd1) : row_ror_i32<2>(dA[q > 0 ? q - 1 : 0]);  // its lanes 14, 15 in lanes 0, 1
+				const int p1 = li == 0 ? e1 : r1;
+				const int p2 = li < 2 ? e2 : r2;
+				const double t0 = bh * (double)dA[q], t1 = bh * (double)p1;
+				P[q] = __builtin_fma(2.0, t1, t0);
+				B2[q] = bh * (double)p2;
+			}
+			// ---- the chain, 4 x 16 samples (whb_chain_asm.h): Y3 = y(-1), Y2 = y(-2) on entry, y(63), y(62) on exit; y of
+			// the lane's sample 16 q + li is captured in Z[q][li & 3]
+			double Y0 = 0.0, Y1 = 0.0, Y2 = y2, Y3 = y1, tt, tq, ym[4];
+			const double y1_in = y1;
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				double z0, z1, z2, z3;
+				asm volatile(TFREC_WHB_CHAIN16_ASM
+					     : [Y0] "+v"(Y0), [Y1] "+v"(Y1), [Y2] "+v"(Y2), [Y3] "+v"(Y3), [Z0] "=&v"(z0), [Z1] "=&v"(z1),
+					       [Z2] "=&v"(z2), [Z3] "=&v"(z3), [T] "=&v"(tt), [Q] "=&v"(tq)
+					     : [a1] "s"(a1), [a2] "s"(a2), [ONE] "v"(1.0), [P] "v"(P[q]), [B] "v"(B2[q]));
+				const int zq = li & 3;
+				ym[q] = zq == 0 ? z0 : (zq == 1 ? z1 : (zq == 2 ? z2 : z3));
+			}
+			// ---- whb.cpp:654 "(int)", :662 "dev < avg_of": the row's 64 decisions against the recorded ones
+			unsigned long long word = 0;
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const unsigned long long b = __ballot(16 * q + li < nv && dA[q] < (int)ym[q]);
+				word |= ((b >> (16 * row)) & 0xffffull) << (16 * q);
+			}
+			const unsigned long long vm = nv >= 64 ? ~0ull : (1ull << nv) - 1ull;
+			bad = bad || ((word ^ recrow[cur.vbase + i]) & vm) != 0ull;
+			// ---- the filter's state after the step's last sample (nv - 1: a window's last step may be partial, and a lock
+			// ends the filter's run at that sample)
+			if (nv == 64) {
+				y1 = Y3;
+				y2 = Y2;
+				fd1 = __builtin_amdgcn_update_dpp(0, dA[3], 0x150 + 15, 0xf, 0xf, true);  // row_newbcast:15
+				fd2 = __builtin_amdgcn_update_dpp(0, dA[3], 0x150 + 14, 0xf, 0xf, true);
+			} else {
+				const int pe = nv - 1, pq = pe >> 4, pb = pe > 0 ? pe - 1 : 0, pbq = pb >> 4;
+				const double ye = pq == 0 ? ym[0] : (pq == 1 ? ym[1] : (pq == 2 ? ym[2] : ym[3]));
+				const double yb = pbq == 0 ? ym[0] : (pbq == 1 ? ym[1] : (pbq == 2 ? ym[2] : ym[3]));
+				const int de = pq == 0 ? dA[0] : (pq == 1 ? dA[1] : (pq == 2 ? dA[2] : dA[3]));
+				const int db = pbq == 0 ? dA[0] : (pbq == 1 ? dA[1] : (pbq == 2 ? dA[2] : dA[3]));
+				const double yl = row_pick_f64(ye, pe & 15), ylb = row_pick_f64(yb, pb & 15);
+				const int dl = row_pick_i32(de, pe & 15), dlb = row_pick_i32(db, pb & 15);
+				y2 = pe > 0 ? ylb : y1_in;
+				y1 = yl;
+				fd2 = pe > 0 ? dlb : fd1;
+				fd1 = dl;
+			}
+			i++;
+			if (i >= nsteps && cur.lock >= 0) {  // the decoder locked on this sample: the average it froze (whb.cpp:653-654)
+				const int delta = (int)y1 - cur.avgf;
+				bad = bad || delta > 1 || delta < -1 || (delta != 0 && (cur.wflags & 1));
+				carry = (cur.wflags & 2) ? 0 : delta;
+			}
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				dA[q] = dB[q];
+		}
+	}
+	if (active && li == 0) {
+		T.whbx0[s] = st;  // the exact state this submit started from (a redo needs it)
+		// a stream whose speculative pass started from a state that a redo has replaced since is redone as well
+		bad = bad || T.whbseen[s] != T.whbgen[s];
+		if (T.whb_force_fail > 0 && (s + T.whb_submit_seq) % T.whb_force_fail == 0)
+			bad = true;  // tests
+		st.y1 = y1;
+		st.y2 = y2;
+		st.fd1 = fd1;
+		st.fd2 = fd2;
+		st.pad_[0] = st.pad_[1] = 0;
+		T.whbx[s] = st;
+		carry_io[s] = bad ? 0 : carry;  // (the exact kernel freezes the exact average: nothing to carry)
+		T.whbfail[s] = bad ? 1 : 0;
+	}
+}
 
 // ------------------------------------------------------------------------------------------------ K5
 // decoder::store_bit / flush for TFA_1 and the TFA_2 family, in two stages:
@@ -2673,6 +3083,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	//   kw : 9 | spec | 10 | repair | 11 | fix | 12          aux: 22 | whb_demod (+ decoder tail) | 13 = 14 = 15
 	//   k2 : 24 | fmdev | 25  (only when the discriminator pass runs here)
 	//   t1 : 16 | mark + slicer | 17 | coop_slicer | 18 | decode | 19 | commit | 20
+	//   vx : 26 | whb_verify | 27
 	auto mark = [&](int k, hipStream_t s_) {
 		if (P.tev)
 			(void)hipEventRecord(P.tev[k], s_);
@@ -2740,6 +3151,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	//   k2 -> cs : TFA_2 family spec -> repair -> fix (biquads) | slicer -> coop_slicer -> decode -> commit
 	//   t1       : TFA_1        mark -> slicer -> coop_slicer -> decode -> commit
 	// ---- WHB
+	int whb_verify = -1;  // the WHB slot, when its speculative stage 2 ran
 	if (has_whb) {
 		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
 		mark(9, P.kw);
@@ -2766,14 +3178,38 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 				static const int whb_lds = std::max(64 * 64, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
 				const dim3 wgrid(n_streams), wblock(64);
 				const int wlds = whb_lds;
-				hipLaunchKernelGGL(whb_demod_kernel, wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams, n_blocks,
-						   sample_base, L, a, T, events, eb, flags);
+				// TFREC_AMD_WHB_EXACT=1: the wave-per-stream recurrence (exact by itself: no verification pass).  BITS mode
+				// (parity / debug) uses it too.
+				static const int whb_exact = env_int("TFREC_AMD_WHB_EXACT", 0, 0, 1);
+				if (whb_exact || (flags & TFREC_AMD_F_BITS)) {
+					hipLaunchKernelGGL((whb_demod_kernel<true, false>), wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams,
+							   n_blocks, sample_base, L, a, T, events, eb, flags);
+				} else {
+					hipLaunchKernelGGL((whb_demod_kernel<false, false>), wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams,
+							   n_blocks, sample_base, L, a, T, events, eb, flags);
+					whb_verify = a;
+				}
 				mark(13, P.aux);
 				mark(14, P.aux);
 				mark(15, P.aux);
 			}
 	}
-	TRY(hipEventRecord(P.done[1], P.aux));
+	if (whb_verify >= 0) {  // stage C of WHB: a serial chain per lane, a few dozen waves
+		if (P.vx != P.aux) {
+			TRY(hipEventRecord(P.ev_aux, P.aux));
+			TRY(hipStreamWaitEvent(P.vx, P.ev_aux, 0));
+		}
+		mark(26, P.vx);
+		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 3) / 4), block, 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
+				   T, P.whb_carry);
+		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly
+		hipLaunchKernelGGL((whb_demod_kernel<true, true>), dim3(n_streams), block, 64 * 64, P.vx, dec, dec_stride, dev32, n_streams,
+				   n_blocks, sample_base, L, whb_verify, T, events, eb, flags);
+		mark(27, P.vx);
+		TRY(hipEventRecord(P.done[1], P.vx));
+	} else {
+		TRY(hipEventRecord(P.done[1], P.aux));
+	}
 	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 64));
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {

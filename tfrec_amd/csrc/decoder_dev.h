@@ -206,13 +206,16 @@ __device__ __forceinline__ void store_bit(Dec &d, int bit)
 
 // decoder::flush as seen from the demodulator: report, then the decoder's own resets
 // (tfa1.cpp:115-117, tfa2.cpp:213-216/276-278, whb.cpp:559-563).
+// Returns the index of the event it appended (-1: none).
 template <int KIND>
-__device__ inline void flush(const EmitCtx &e, Dec &d, long long rssi_raw, int offset, int g)
+__device__ inline int flush(const EmitCtx &e, Dec &d, long long rssi_raw, int offset, int g)
 {
 	const int verdict = flush_verdict<KIND>(d.rdata, d.byte_cnt, e.sensor_type);
+	int ev_idx = -1;
 	if (!e.quiet && ((e.flags & TFREC_AMD_F_ALL_FLUSHES) || verdict != 0)) {
 		const uint32_t idx = atomicAdd(&e.eb->count, 1u);
 		if (idx < e.eb->capacity) {
+			ev_idx = (int)idx;
 			tfrec_amd_event *ev = e.events + idx;
 			ev->stream = e.stream;
 			ev->slot = (uint8_t)e.slot;
@@ -240,6 +243,7 @@ __device__ inline void flush(const EmitCtx &e, Dec &d, long long rssi_raw, int o
 		if (KIND == 2)
 			d.synced = 0;
 	}
+	return ev_idx;
 }
 
 }  // namespace tfrec

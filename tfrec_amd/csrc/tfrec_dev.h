@@ -115,7 +115,7 @@ struct EventBuf {
 	// doubled its registers: 0.8 ms per batch): (stream << 32 | sample) of every flagged sample; more than
 	// kFmListCap pending = the resolve kernel rescans the whole submit instead
 	uint32_t fm_pending;
-	uint32_t pad_;
+	uint32_t dead;  // events marked TFREC_AMD_STATUS_DEAD (a WHB stream's speculative events, replaced by the exact kernel's)
 	unsigned long long fm_list[256];
 };
 constexpr int kFmListCap = 256;
@@ -151,6 +151,14 @@ struct WhbStart {
 	uint32_t sr, lfsr;
 	int32_t sr_cnt, byte_cnt, synced;
 	int32_t pad_[3];
+};
+
+// iir_avg of whb_demod (whb.cpp:611, 654) as whb_verify_kernel carries it: the last two outputs, bit for bit, and the
+// last two inputs (0.5 * a stage-1 output each) as the integers
+struct WhbExact {
+	double y1, y2;
+	int32_t fd1, fd2;
+	int32_t pad_[2];
 };
 
 // TFA_1 peak detector (tfa1.cpp:157-160) over one piece of kMarkSlots slots of a long window, run by mark_kernel
@@ -211,7 +219,22 @@ struct WinTables {
 	const uint32_t *prevdec;  // [n_streams] the decimated sample before this submit's first one (front end)
 	int32_t *timeout_carry; // [chains] timeout_cnt the window scan carries from submit to submit (ONE array per context,
 	                        // shared by the two table sets: the scan of submit k+1 must not wait for the chains of k)
+	// WHB stage 2, speculate + verify (chains2.hip K4'): per 64-sample step in which the decision-level average ran,
+	// the decisions "dev < (int)avg" the demodulator kernel took from its lane-parallel evaluation of the filter
+	unsigned long long *whbrec;  // [n_streams * whbrec_stride]
+	int32_t whbrec_stride;       // filter steps a stream can have in one submit (M / 64 + cap + 2)
+	WhbExact *whbx;              // [n_streams] the filter's exact state, carried by whb_verify_kernel (ONE array per context)
+	int32_t *whbfail;            // [n_streams] set by whb_verify_kernel: the stream's speculation failed in this submit
+	// ... and what the exact kernel needs to do such a stream's submit again:
+	ChainState *whbsnap;         // [n_streams] the WHB chain state whb_demod_kernel<false> started this submit from
+	WhbExact *whbx0;             // [n_streams] the exact filter state whb_verify_kernel started this submit from
+	uint32_t *whbseen;           // [n_streams] whbgen[s] as whb_demod_kernel<false> saw it before it read the state
+	uint32_t *whbgen;            // [n_streams] redone submits of the stream so far (ONE array per context)
+	ChainState *whbX;            // [n_streams] the chain state after the stream's last redone submit (ONE array per context)
+	int32_t whb_force_fail;      // tests (TFREC_AMD_WHB_FORCE_FAIL=N): declare every N-th (stream + submit) failed
+	int32_t whb_submit_seq;
 };
+constexpr int kStatusDead = 0xff;  // tfrec_amd_event::status of a retracted event: never reported
 
 // Streams and events of one submit of the window-parallel pipeline.  Every (protocol family, stage) pair owns a
 // stream, so that stage A (biquads) of submit k+1 runs beside stage B (slicers, decoders) of submit k; the two
@@ -223,6 +246,9 @@ struct PipeCtl {
 	hipEvent_t ev_front;       // front end done (fs)
 	hipStream_t k2, kw;        // stage A: biquads of the TFA_2 family / of WHB
 	hipStream_t cs, aux, t1;   // stage B: TFA_2 family, WHB, TFA_1 (no stage A)
+	hipStream_t vx;            // stage C of WHB: whb_verify_kernel (== aux in the shallow layout)
+	hipEvent_t ev_aux;         // whb_demod_kernel done (aux)
+	int *whb_carry;            // [n_streams] whb_verify_kernel: exact minus speculated frozen average of a window still open
 	hipEvent_t ev_win;         // window scan done (fs)
 	hipEvent_t ev_fork;        // first TFA_2 biquad pass done (k2): TFA_1 starts
 	hipEvent_t ev_k2, ev_kw;   // stage A done
@@ -235,7 +261,7 @@ struct PipeCtl {
 	int16_t *fmdev_out;
 	const uint32_t *prevdec;
 };
-constexpr int kTimingMarks = 26;
+constexpr int kTimingMarks = 28;
 
 constexpr int kNQueues = 8;
 // one more counter after the work queues, with a (stream, slot) list behind the queues' items: the TFA_2-family
