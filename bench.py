@@ -11,12 +11,15 @@ fixed threshold -t 500, per GPU.  With N GPUs every rank gets its own 1024 strea
 8192 streams, weak scaling, no collective on the data path -- streams are independent).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     dominant kernel vs the HBM roofline (algorithmic bytes = 2 B per complex input sample), the whole
-                  path's fraction, measured HBM traffic (profiles/r02_traffic.json),
+  "roofline":     dominant kernel (longest live HIP-event span) vs the HBM roofline (algorithmic bytes = 2 B per complex input
+                  sample), the whole path's fraction; from the builder's committed rocprofv3 runs of this command (named in the
+                  block): that kernel's average in the kernel trace, HBM traffic, and "valu" = the batch's VALU instruction mix
+                  against the measured issue cost per class ("state both numbers"),
   "cpu_baseline": the reference CPU path timed on this box's host cores (1 thread) on a bounded sample,
   "h2d_included": the same batches fed from page-locked HOST memory through the submit/drain FIFO (PCIe-inclusive rate;
                   never `value`),
-  "ms_min/ms_median/ms_max": per-step dispersion (time between consecutive drains inside the timed region).
+  "ms_min/ms_median/ms_max": per-step dispersion (time between consecutive drains inside the timed region);
+  "ms_per_step_steady": the same without the steps in which the FIFO fills and drains.
 Parity gate (before the timed region, on fresh state): EVERY stream of the batch at N=1 (128 spread over the batch per
 rank at N>1) against the CPU oracle; after the timed region the discriminator's self-check counters
 (config.atan_*: samples decided by the exact slow path / differing from this host's libm) -- a mismatch fails the run.
@@ -116,6 +119,17 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
     except Exception as e:
         res["all_cores_error"] = str(e)[:200]
     return res
+
+
+def a_steps_in_profile(root, ptag):
+    """launches of the front end in the committed kernel trace = batches it covers"""
+    try:
+        for ln in open(os.path.join(root, "profiles", ptag + "_kernel_stats.txt")):
+            if "frontend_kernel" in ln:
+                return int(ln.split()[-4])
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -388,16 +402,49 @@ def main():
         dom_ms = kms[dom_name]
         alg_bytes = 2.0 * samples_per_step_gpu  # 2 B per complex input sample, one launch = one batch
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_traffic.json, collected and corrected as
-        # MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)
-        traffic = traffic_total = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            if (tj.get("streams"), tj.get("blocks"), tj.get("types")) == (n_streams, n_blocks, a.types):
+        # What this run cannot measure itself comes from the builder's committed rocprofv3 runs of the SAME command
+        # (profiles/run_round3.sh; named in `profiles` / `traffic_source`): the kernel's average duration in the kernel
+        # trace, HBM bytes per launch (separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes
+        # and calibrated per access pattern), and the batch's VALU instruction mix for the VALU-issue roof.
+        traffic = traffic_total = prof_ms = traffic_source = None
+        valu = None
+        same_workload = (n_streams, n_blocks, a.types, rate) == (1024, 48, 0x2F, 1)
+        ptag = next((t for t in ("r03_final", "r03_mid") if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
+        if ptag and same_workload:
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_traffic.json")))
                 traffic = tj["kernels"].get(dom_name, {}).get("hbm_bytes")
                 traffic_total = tj.get("total_hbm_bytes_per_batch")
-        except Exception:
-            pass
+                traffic_source = "profiles/%s_traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % ptag
+            except Exception:
+                pass
+            try:  # "tfrec::frontend_kernel<false> ... calls total avg pct": the trace's average for the dominant kernel
+                short = dom_name.replace("_kernel", "")
+                cand = []
+                for ln in open(os.path.join(ROOT, "profiles", ptag + "_kernel_stats.txt")):
+                    f = ln.split()
+                    if len(f) >= 5 and ("tfrec::%s_kernel" % short) in ln and f[-4].isdigit():
+                        cand.append((float(f[-3]), float(f[-2])))
+                if cand:  # (several template instances of one kernel: all launches of a batch together)
+                    calls = max(1, sum(1 for _ in cand))
+                    prof_ms = round(sum(t for t, _ in cand) / 1e3 / (a_steps_in_profile(ROOT, ptag) or 1), 4)
+            except Exception:
+                pass
+            try:
+                vj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_valu.json")))
+                valu = {
+                    "insts_per_batch": {k: int(v) for k, v in vj["per_batch"].items()},
+                    "cycles_per_instruction_per_simd": vj["cycles_per_instruction_per_simd"],
+                    "roof_ms": vj["valu_roof_ms"], "salu_roof_ms": vj["salu_roof_ms"],
+                    "frac": round(vj["valu_roof_ms"] / (elapsed / a.steps * 1e3), 4),
+                    "sum_of_kernel_ms_alone": vj["sum_of_kernel_ms_alone"],
+                    "how": "VALU wave-instructions of one batch by class (rocprofv3 --pmc, profiles/%s_pmc_mix.txt) x the measured "
+                           "issue cost per class with 8 waves per SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl) "
+                           "/ (1024 SIMDs x 2.4 GHz); frac = that / ms_per_step; per-kernel counter-derived VALU busy: profiles/%s_valu.json"
+                           % (ptag, ptag, ptag),
+                }
+            except Exception:
+                pass
         out = {
             "metric": "IQ MSamples/s through demod+decode (batched streams)",
             "value": round(value, 3),
@@ -408,6 +455,8 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "ms_min": round(float(step_ms.min()), 4), "ms_median": round(float(np.median(step_ms)), 4),
             "ms_max": round(float(step_ms.max()), 4),
+            # without the steps in which the FIFO of `depth` batches fills and drains (the timed region starts and ends empty)
+            "ms_per_step_steady": (round(float(step_ms[depth:-depth].mean()), 4) if len(step_ms) > 2 * depth + 2 else None),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -432,7 +481,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                # the dominant kernel's duration: live HIP events on its stream (includes its wait for the chip beside the
+                # other streams' kernels) | average of the same kernel in the committed kernel trace, per batch
+                "kernel_ms_hip_events": round(dom_ms, 4), "kernel_ms_profiles": prof_ms,
+                "profiles": ("profiles/%s_kernel_stats.txt" % ptag) if ptag and same_workload else None,
+                "valu": valu,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "whole_path_frac": round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
                 "traffic_total": traffic_total,

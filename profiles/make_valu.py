@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""VALU work of one batch from two rocprofv3 PMC passes (profiles/run_valu.sh) + the measured issue cost per instruction
+class (profiles/ubench/valu_issue.hip, 8 waves per SIMD) -> the VALU-issue roof of bench.py's roofline.valu block.
+usage: make_valu.py <pmc_valu.txt> <pmc_mix.txt> <valu_issue.jsonl> <out.json>
+
+Per kernel (dispatches are serialised by the counter collection: the kernel's own figures):
+  valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)   (SQ_ACTIVE_INST_* count quad-cycles)
+Per batch (one batch = one frontend launch):
+  issue_cycles = sum over classes of instructions x measured cycles per instruction and SIMD with 8 waves per SIMD
+  valu_roof_ms = issue_cycles / (1024 SIMDs x 2.4 GHz)
+"""
+import json, re, sys
+
+CLOCK_GHZ = 2.4
+N_SIMD = 1024
+
+
+def parse(path):
+    out = {}
+    for ln in open(path):
+        m = re.match(r"(.+?)\s+dispatches=(\d+)\s+(.*)", ln)
+        if not m:
+            continue
+        name = m.group(1).strip().replace("void ", "").replace("tfrec::", "")
+        d = {k: float(v) for k, v in (kv.split("=") for kv in m.group(3).split())}
+        d["dispatches"] = int(m.group(2))
+        out.setdefault(name, []).append(d)
+    return out
+
+
+valu, mix = parse(sys.argv[1]), parse(sys.argv[2])
+cost = {}
+for ln in open(sys.argv[3]):
+    ln = ln.strip()
+    if ln.startswith("{"):
+        j = json.loads(ln)
+        if j["waves_per_simd"] == 8:
+            cost[j["class"]] = j["cycles_per_inst_per_simd"]
+cls_cost = {"fp64": cost["v_fma_f64"], "fma_f32": cost["v_pk_fma_f32"], "cvt": cost["v_cvt_f64_i32"], "int32": cost["v_add_u32"],
+            "other": cost["v_fma_f32"], "salu": cost["s_add_u32"]}
+nb = max(d["dispatches"] for n, ds in valu.items() if n.startswith("frontend_kernel") for d in ds)
+kernels = {}
+tot = dict(valu=0.0, fp64=0.0, fma_f32=0.0, cvt=0.0, int32=0.0, other=0.0, salu=0.0)
+for name, ds in valu.items():
+    if name.startswith("__"):
+        continue
+    for k, d in enumerate(ds):  # (names truncated to 34 characters: several template instances may share one)
+        mx = mix.get(name, [{}] * len(ds))[k] if k < len(mix.get(name, [])) else {}
+        per = d["dispatches"] / nb
+        fp64 = mx.get("SQ_INSTS_VALU_FMA_F64", 0) + mx.get("SQ_INSTS_VALU_ADD_F64", 0) + mx.get("SQ_INSTS_VALU_MUL_F64", 0)
+        f32 = mx.get("SQ_INSTS_VALU_FMA_F32", 0)
+        cvt = mx.get("SQ_INSTS_VALU_CVT", 0)
+        i32 = mx.get("SQ_INSTS_VALU_INT32", 0)
+        nv = d.get("SQ_INSTS_VALU", 0)
+        other = max(0.0, nv - fp64 - f32 - cvt - i32)
+        gui_cycles = d.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        key = name if len(ds) == 1 else "%s #%d" % (name, k)
+        kernels[key] = dict(launches_per_batch=round(per, 2), insts_valu=nv, insts_salu=d.get("SQ_INSTS_SALU", 0), fp64=fp64,
+                            fma_f32=f32, cvt=cvt, int32=i32, other=other, kernel_cycles_alone=gui_cycles,
+                            kernel_ms_alone=round(gui_cycles / (CLOCK_GHZ * 1e6), 4),
+                            valu_busy=round(4.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, gui_cycles * N_SIMD), 4))
+        for c, v in (("valu", nv), ("fp64", fp64), ("fma_f32", f32), ("cvt", cvt), ("int32", i32), ("other", other),
+                     ("salu", d.get("SQ_INSTS_SALU", 0))):
+            tot[c] += v * per
+issue = sum(tot[c] * cls_cost[c] for c in ("fp64", "fma_f32", "cvt", "int32", "other"))
+out = dict(note=__doc__.strip(), cycles_per_instruction_per_simd=cls_cost, per_batch=tot, valu_issue_cycles_per_batch=issue,
+           valu_roof_ms=round(issue / (N_SIMD * CLOCK_GHZ * 1e6), 4),
+           salu_roof_ms=round(tot["salu"] * cls_cost["salu"] / (N_SIMD * CLOCK_GHZ * 1e6), 4),
+           sum_of_kernel_ms_alone=round(sum(k["kernel_ms_alone"] * k["launches_per_batch"] for k in kernels.values()), 3),
+           kernels=kernels)
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("per_batch", "valu_roof_ms", "salu_roof_ms", "sum_of_kernel_ms_alone")}, indent=1))

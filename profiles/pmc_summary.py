@@ -10,4 +10,4 @@ for r in csv.DictReader(open(f)):
     n[k].add(r["Dispatch_Id"])
 for k, v in sorted(agg.items()):
     d = max(len(n[k]), 1)
-    print("%-34s dispatches=%d  " % (k[:34], d) + "  ".join("%s=%.4g" % (c, x / d) for c, x in sorted(v.items())))
+    print("%-44s dispatches=%d  " % (k[:44], d) + "  ".join("%s=%.4g" % (c, x / d) for c, x in sorted(v.items())))

@@ -84,7 +84,7 @@ struct tfrec_amd_ctx {
 	bool scan_on_kw = false;                      // deep layout: the window scan runs at the head of kw, not on fs
 	bool fmdev_k2 = false;                        // the discriminator pass runs at the head of k2, not behind the front end
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
-	hipEvent_t ev_pipe[kSets][4] = {};                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
+	hipEvent_t ev_pipe[kSets][5] = {};                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
 	// one set per submit in flight, like the front-end outputs: the window scan and the biquads of submit k+1 fill
 	// theirs while the slicers of submit k still read the other
@@ -767,6 +767,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.ev_fork = c->ev_pipe[set][1];
 		P.ev_k2 = c->ev_pipe[set][2];
 		P.ev_kw = c->ev_pipe[set][3];
+		P.ev_fm = c->ev_pipe[set][4];
 		for (int k = 0; k < 3; k++)
 			P.done[k] = c->done[set][k];
 		P.tev = (timing && c->tev[set][0]) ? c->tev[set] : nullptr;

@@ -49,6 +49,17 @@ static int env_int(const char *name, int dflt, int lo = 0, int hi = 1 << 30)
 
 constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
 
+// Wave priority of the LATENCY-bound kernels (serial chains per lane or per wave: slicers, WHB stage 2 and its check):
+// experiment knob, see DESIGN.md 7d
+#ifndef TFREC_AMD_LAT_PRIO
+#define TFREC_AMD_LAT_PRIO 0
+#endif
+__device__ __forceinline__ void latency_prio()
+{
+	if (TFREC_AMD_LAT_PRIO > 0)
+		__builtin_amdgcn_s_setprio(TFREC_AMD_LAT_PRIO);
+}
+
 // demodulator::start (decoder.cpp:118-122) applied once per block boundary between two blocks
 __device__ __forceinline__ int rebase_lbi(int lbi, int from_block, int to_block)
 {
@@ -1191,6 +1202,7 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 						    WinTables T, int lanes, int head_chunks, int kind)
 {
 	__shared__ uint4 slot_lds[8 * 64];
+	latency_prio();
 	uint4 *my_lds = slot_lds + threadIdx.x;
 	if ((int)threadIdx.x >= lanes)
 		return;
@@ -1225,6 +1237,7 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 __global__ __launch_bounds__(64) void mark_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
 						  int n_blocks, ChainLaunch L, WinTables T)
 {
+	latency_prio();
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const uint32_t count = T.queue[7].count;
@@ -1668,6 +1681,7 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 							 ChainLaunch L, WinTables T, int kind)
 {
 	__shared__ int lds_m[64];
+	latency_prio();
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int q = 2 * kind;  // the long windows of this kind
@@ -2062,6 +2076,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 64 B, used by the decoder tail
 #ifdef TFREC_AMD_WHB_PRIO
 	__builtin_amdgcn_s_setprio(TFREC_AMD_WHB_PRIO);
+#else
+	latency_prio();
 #endif
 	// One of these waves per SIMD, never two: the kernel claims 264 of a SIMD's 512 registers (256 + 8 accumulation
 	// registers it never touches).  Its one-wave workgroups are dispatched while the other chains' kernels fill the chip
@@ -2606,7 +2622,11 @@ __device__ __forceinline__ double row_pick_f64(double v, int src)
 __global__ __launch_bounds__(64) void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 							ChainLaunch L, int a, WinTables T, int *__restrict__ carry_io)
 {
-	__builtin_amdgcn_s_setprio(1);
+#ifdef TFREC_AMD_VERIFY_PRIO
+	__builtin_amdgcn_s_setprio(TFREC_AMD_VERIFY_PRIO);
+#else
+	__builtin_amdgcn_s_setprio(TFREC_AMD_LAT_PRIO > 1 ? TFREC_AMD_LAT_PRIO : 1);
+#endif
 	const int M = n_blocks * kBlockDec;
 	const int ln = threadIdx.x, row = ln >> 4, li = ln & 15;
 	const int s = blockIdx.x * 4 + row;
@@ -3152,8 +3172,19 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	//   t1       : TFA_1        mark -> slicer -> coop_slicer -> decode -> commit
 	// ---- WHB
 	int whb_verify = -1;  // the WHB slot, when its speculative stage 2 ran
+	// The discriminator pass (only the TFA_2 family reads its output) at the head of kw instead of k2: with the WHB stage 2
+	// speculated, k2 (discriminator + three biquad passes + verify) was the longest stream of the batch and kw half idle
+	static const int fmdev_kw = env_int("TFREC_AMD_FMDEV_KW", 0, 0, 1);  // (measured: 8.2 instead of 7.3 ms per batch -- the pass stretches to 5 ms there)
+	const bool fm_on_kw = fmdev_kw && has_whb && has_tfa2 && P.fmdev_wmax > 0 && P.kw != P.k2;
 	if (has_whb) {
 		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
+		if (fm_on_kw) {
+			mark(24, P.kw);
+			TRY(launch_fmdev(P.kw, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,
+					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));
+			mark(25, P.kw);
+			TRY(hipEventRecord(P.ev_fm, P.kw));
+		}
 		mark(9, P.kw);
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(spec_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
@@ -3235,7 +3266,9 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	bool t1_waits = false;
 	if (has_tfa2) {
 		TRY(hipStreamWaitEvent(P.k2, P.ev_win, 0));
-		if (P.fmdev_wmax > 0) {
+		if (fm_on_kw) {
+			TRY(hipStreamWaitEvent(P.k2, P.ev_fm, 0));
+		} else if (P.fmdev_wmax > 0) {
 			mark(24, P.k2);
 			TRY(launch_fmdev(P.k2, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,
 					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));

@@ -252,6 +252,7 @@ struct PipeCtl {
 	hipEvent_t ev_win;         // window scan done (fs)
 	hipEvent_t ev_fork;        // first TFA_2 biquad pass done (k2): TFA_1 starts
 	hipEvent_t ev_k2, ev_kw;   // stage A done
+	hipEvent_t ev_fm;          // the discriminator pass done, when it runs at the head of kw instead of k2
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
 	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
 	// the FM discriminator pass, when it runs at the head of stage A of the TFA_2 family (k2) instead of behind the
