@@ -198,7 +198,8 @@ int tfrec_amd_get_fm_stats(tfrec_amd_ctx *ctx, tfrec_amd_fm_stats *out);
 int tfrec_amd_atan_uncertain(tfrec_amd_ctx *ctx, uint64_t *n);
 /* Parity probe: the device's fm_dev on n 16-byte records -- kind 0: int32 quadruples (ar, aj, br, bj) = the arguments
  * of dsp_stuff.cpp:284; kind 1: int64 pairs (cr, cj) = its cross terms (:288-289), for directions no int16 quadruple
- * reaches.  out[n].  No context needed.  stats (may be NULL): as above, for this call. */
+ * reaches; kind 2: the device's fm_dev_nrzs (dsp_stuff.cpp:269-279, with its +-1e9 clamp) on int32 quadruples.
+ * out[n].  No context needed.  stats (may be NULL): as above, for this call. */
 int tfrec_amd_fm_dev_probe(int device, int kind, const void *records, size_t n, int32_t *out, tfrec_amd_fm_stats *stats);
 int tfrec_amd_get_timings(tfrec_amd_ctx *ctx, tfrec_amd_timings *out);
 /* Cumulative counters of the speculative stages (window-parallel pipeline only).  They only describe how the work

@@ -3,6 +3,8 @@
 Integer / byte / index work => equality, no tolerance.  The only floating point on the path (fp64
 discriminator + biquads) feeds integer truncations; those integers are compared exactly too.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -583,3 +585,13 @@ def test_whb_speculation_is_verified_and_rarely_fails():
         ev = r.drain()
         assert _all_streams_equal(ev, iq, 0x20, 500) > n_streams
         assert r.stats()["whb_respeculated"] <= 1
+
+
+def test_fm_dev_nrzs_probe_equals_the_real_reference(golden_dir):
+    """fm_dev_nrzs (dsp_stuff.cpp:269-279) on the device, including the +-1e9 clamp (101 of the golden inputs reach it;
+    no int16 sample pair does): the probes of the REAL reference function (tests/golden/unit_probes.npz)."""
+    z = np.load(os.path.join(golden_dir, "unit_probes.npz"))
+    got = api.fm_dev_nrzs_probe(z["fm_in"])
+    want = z["fm_out"][:, 1]
+    assert np.array_equal(got, want)
+    assert (np.abs(want) == 1000000000).sum() >= 100

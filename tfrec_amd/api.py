@@ -275,6 +275,15 @@ class Receiver:
         return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:7]}
 
 
+def fm_dev_nrzs_probe(records: np.ndarray, device: int = 0) -> np.ndarray:
+    """The device's fm_dev_nrzs (dsp_stuff.cpp:269-279) on int32 quadruples [n, 4] = (ar, aj, br, bj) -> int32[n]."""
+    L = load_library()
+    q = np.ascontiguousarray(records, dtype=np.int32).reshape(-1, 4)
+    out = np.empty(len(q), dtype=np.int32)
+    _check(L, L.tfrec_amd_fm_dev_probe(device, 2, q.ctypes.data, len(q), out.ctypes.data, None))
+    return out
+
+
 def fm_dev_probe(records: np.ndarray, device: int = 0, cross: bool = False):
     """The device's fm_dev (dsp_stuff.cpp:284-292) on int32 quadruples [n, 4] = (ar, aj, br, bj), or (cross=True) on
     int64 cross terms [n, 2] = (cr, cj) -> (int32[n], stats)."""

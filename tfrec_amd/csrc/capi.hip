@@ -84,7 +84,8 @@ struct tfrec_amd_ctx {
 	bool scan_on_kw = false;                      // deep layout: the window scan runs at the head of kw, not on fs
 	bool fmdev_k2 = false;                        // the discriminator pass runs at the head of k2, not behind the front end
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
-	hipEvent_t ev_pipe[kSets][5] = {};                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
+	hipEvent_t ev_pipe[kSets][7] = {};
+	hipStream_t cz = nullptr;                    // PipeCtl::cz (TFREC_AMD_COOP_STREAM)                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
 	// one set per submit in flight, like the front-end outputs: the window scan and the biquads of submit k+1 fill
 	// theirs while the slicers of submit k still read the other
@@ -297,6 +298,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 				(void)hipEventDestroy(e);
 	}
 	(void)hipFree(c->d_tcarry);
+	if (c->cz)
+		(void)hipStreamDestroy(c->cz);
 	(void)hipFree(c->d_whbx);
 	(void)hipFree(c->d_whbcarry);
 	(void)hipFree(c->d_whbgen);
@@ -654,6 +657,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    (hipStreamCreateWithFlags(&c->k2, hipStreamNonBlocking) != hipSuccess ||
 		     hipStreamCreateWithFlags(&c->kw, hipStreamNonBlocking) != hipSuccess))
 			rc = TFREC_AMD_E_HIP;
+		// TFREC_AMD_COOP_STREAM=1: a stream for the TFA_2 family's cooperative slicers (PipeCtl::cz).  It is the fifth of high
+		// priority: with the HIP default of four hardware queues per priority it shares one (GPU_MAX_HW_QUEUES >= 8 wanted).
+		if (c->deep && rc == TFREC_AMD_OK && getenv("TFREC_AMD_COOP_STREAM") && atoi(getenv("TFREC_AMD_COOP_STREAM")) != 0 &&
+		    hipStreamCreateWithPriority(&c->cz, hipStreamNonBlocking, atoi(getenv("TFREC_AMD_COOP_STREAM")) == 2 ? 0 : prio_hi) != hipSuccess)
+			rc = TFREC_AMD_E_HIP;
 		// whb_verify_kernel runs on the copy stream, ahead of its submit's device-to-host copies (they wait for it anyway).
 		// A stream of its own would be the FIFTH of normal priority in the process (k2, kw, cp and the caller's): it shared a
 		// hardware queue with kw, and the 6 ms verification of submit k held up the WHB biquads of submit k + 2.
@@ -768,6 +776,9 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.ev_k2 = c->ev_pipe[set][2];
 		P.ev_kw = c->ev_pipe[set][3];
 		P.ev_fm = c->ev_pipe[set][4];
+		P.cz = c->cz;
+		P.ev_heads = c->ev_pipe[set][5];
+		P.ev_coop = c->ev_pipe[set][6];
 		for (int k = 0; k < 3; k++)
 			P.done[k] = c->done[set][k];
 		P.tev = (timing && c->tev[set][0]) ? c->tev[set] : nullptr;
@@ -869,7 +880,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->aux, c->vx, c->t1, c->cp })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;
@@ -1044,7 +1055,7 @@ int tfrec_amd_get_fm_stats(tfrec_amd_ctx *c, tfrec_amd_fm_stats *out)
 int tfrec_amd_fm_dev_probe(int device, int kind, const void *quads_v, size_t n, int32_t *out, tfrec_amd_fm_stats *stats)
 {
 	const int32_t *quads = (const int32_t *)quads_v;
-	if (!quads || !out || n == 0 || n > (1u << 26) || kind < 0 || kind > 1)
+	if (!quads || !out || n == 0 || n > (1u << 26) || kind < 0 || kind > 2)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(device));
 	int32_t *d_q = nullptr, *d_o = nullptr;
@@ -1160,6 +1171,8 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 			HIPCHK(hipEventElapsedTime(k2_ms[k], tev[1 + k], tev[2 + k]));
 		HIPCHK(hipEventElapsedTime(&out->slicer_ms, tev[23], tev[5]));
 		HIPCHK(hipEventElapsedTime(&out->coop_slicer_ms, tev[5], tev[6]));
+		if (c->cz)  // (split off cs: its own marks)
+			HIPCHK(hipEventElapsedTime(&out->coop_slicer_ms, tev[28], tev[29]));
 		HIPCHK(hipEventElapsedTime(&out->decode_ms, tev[6], tev[7]));
 		HIPCHK(hipEventElapsedTime(&out->commit_ms, tev[7], tev[8]));
 	}

@@ -54,6 +54,12 @@ constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
 #ifndef TFREC_AMD_LAT_PRIO
 #define TFREC_AMD_LAT_PRIO 0
 #endif
+// experiment: cap the registers of the latency-bound kernels (more waves of the throughput kernels fit beside them)
+#ifdef TFREC_AMD_LAT_VGPRS
+#define TFREC_LAT_VGPR_ATTR __attribute__((amdgpu_num_vgpr(TFREC_AMD_LAT_VGPRS)))
+#else
+#define TFREC_LAT_VGPR_ATTR
+#endif
 __device__ __forceinline__ void latency_prio()
 {
 	if (TFREC_AMD_LAT_PRIO > 0)
@@ -1197,11 +1203,15 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 // windows are sliced completely.  Of the long TFA_2-family windows only the head, where the thresholds still
 // adapt sample by sample (tfa2.cpp:363 "bitcnt < 10"; cheap per window when 64 windows share a wave, expensive
 // for a whole wave) -- the rest, and the long TFA_1 windows, belong to coop_slicer_kernel.
-__global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+__global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void slicer_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 						    const int16_t *__restrict__ ld16, int n_streams, int n_blocks, ChainLaunch L,
-						    WinTables T, int lanes, int head_chunks, int kind)
+						    WinTables T, int lanes, int head_chunks, int kind, int qsel)
 {
-	__shared__ uint4 slot_lds[8 * 64];
+	// qsel: 0 = long windows (heads), then short ones; 1 = only the long windows' heads; 2 = only the short windows
+	// the lanes' 32-sample chunk, a column each: 8 KB for TFA_1 (32 dwords per lane), 4 KB for the TFA_2 family (32 int16).
+	// Dynamic, so that the TFA_2-family launch holds half: these waves live for milliseconds, six of them per CU, and the
+	// front end beside them needs 16.6 KB per workgroup of what the CU's 160 KB have left
+	extern __shared__ uint4 slot_lds[];
 	latency_prio();
 	uint4 *my_lds = slot_lds + threadIdx.x;
 	if ((int)threadIdx.x >= lanes)
@@ -1209,6 +1219,8 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	for (int q = 2 * kind + (kind == 0 ? 1 : 0); q < 2 * kind + 2; q++) {
+		if ((qsel == 1 && (q & 1)) || (qsel == 2 && !(q & 1)))
+			continue;
 		const uint32_t count = T.queue[q].count;
 		const int head = (q & 1) == 0 ? head_chunks : 0;
 		while (true) {
@@ -1234,7 +1246,7 @@ __global__ __launch_bounds__(64) void slicer_kernel(const uint32_t *__restrict__
 // start == the true value bit for bit when it reaches the piece, and otherwise recomputes the piece itself:
 // exactness does not rest on the warm-up, only speed does.  16 lane-instructions per sample for 64 pieces at once
 // instead of 7 wave-instructions per sample.
-__global__ __launch_bounds__(64) void mark_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
+__global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void mark_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
 						  int n_blocks, ChainLaunch L, WinTables T)
 {
 	latency_prio();
@@ -2619,7 +2631,7 @@ __device__ __forceinline__ double row_pick_f64(double v, int src)
 	return __hiloint2double(row_pick_i32(__double2hiint(v), src), row_pick_i32(__double2loint(v), src));
 }
 
-__global__ __launch_bounds__(64) void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
+__global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 							ChainLaunch L, int a, WinTables T, int *__restrict__ carry_io)
 {
 #ifdef TFREC_AMD_VERIFY_PRIO
@@ -3103,11 +3115,13 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	//   kw : 9 | spec | 10 | repair | 11 | fix | 12          aux: 22 | whb_demod (+ decoder tail) | 13 = 14 = 15
 	//   k2 : 24 | fmdev | 25  (only when the discriminator pass runs here)
 	//   t1 : 16 | mark + slicer | 17 | coop_slicer | 18 | decode | 19 | commit | 20
-	//   vx : 26 | whb_verify | 27
+	//   vx : 26 | whb_verify | 27          cz : 28 | coop_slicer (TFA_2 family, when split off cs) | 29
 	auto mark = [&](int k, hipStream_t s_) {
 		if (P.tev)
 			(void)hipEventRecord(P.tev[k], s_);
 	};
+	// WHAT-IF experiments only (results are wrong): leave kernels out to see what each costs the batch period
+	static const int skip = env_int("TFREC_AMD_SKIP", 0, 0, 1 << 16);
 	hipError_t e = hipSuccess;
 #define TRY(x)                          \
 	do {                            \
@@ -3186,11 +3200,14 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipEventRecord(P.ev_fm, P.kw));
 		}
 		mark(9, P.kw);
+		if (!(skip & 256))
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(spec_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(10, P.kw);
+		if (!(skip & 256))
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
+		if (!(skip & 256))
 		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(11, P.kw);
@@ -3216,6 +3233,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 					hipLaunchKernelGGL((whb_demod_kernel<true, false>), wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams,
 							   n_blocks, sample_base, L, a, T, events, eb, flags);
 				} else {
+					if (!(skip & 32))
 					hipLaunchKernelGGL((whb_demod_kernel<false, false>), wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams,
 							   n_blocks, sample_base, L, a, T, events, eb, flags);
 					whb_verify = a;
@@ -3231,6 +3249,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.vx, P.ev_aux, 0));
 		}
 		mark(26, P.vx);
+		if (!(skip & 16))
 		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 3) / 4), block, 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
 				   T, P.whb_carry);
 		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly
@@ -3245,13 +3264,40 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
 		if (kind == 0)
+			if (!(skip & 8))
 			hipLaunchKernelGGL(mark_kernel, dim3(std::max(1, win_blocks / 4)), block, 0, s_, dec, dec_stride, n_streams,
 					   n_blocks, L, T);
-		hipLaunchKernelGGL(slicer_kernel, dim3(win_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
-				   lanes_win, head_chunks, kind);
-		mark(m0 + 1, s_);
-		hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L,
-				   T, kind);
+		// The lanes take their windows from a queue, so the wave count is a free parameter: fewer waves = fewer registers
+		// held for milliseconds by a latency-bound kernel (the front end beside it lives on what is left), more windows per lane
+		static const int slicer_div = env_int("TFREC_AMD_SLICER_DIV", 1, 1, 64);
+		const size_t slds = (kind == 0 ? 8 : 4) * 64 * sizeof(uint4);
+		const bool split = kind == 1 && P.cz != nullptr;
+		if (split) {
+			// the long windows' heads first (few windows: a small grid), then -- beside each other -- their tails on cz and
+			// the short windows here: stage B of the TFA_2 family was the longest chain of the batch (slicers 3.5 ms +
+			// cooperative slicers 2.6 ms, one after the other)
+			hipLaunchKernelGGL(slicer_kernel, dim3(std::max(64, win_blocks / 8)), block, slds, s_, dec, dec_stride, ld16, n_streams,
+					   n_blocks, L, T, lanes_win, head_chunks, kind, 1);
+			(void)hipEventRecord(P.ev_heads, s_);
+			(void)hipStreamWaitEvent(P.cz, P.ev_heads, 0);
+			mark(28, P.cz);
+			hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks), block, 0, P.cz, dec, dec_stride, ld16, n_streams, n_blocks, L,
+					   T, kind);
+			mark(29, P.cz);
+			(void)hipEventRecord(P.ev_coop, P.cz);
+			hipLaunchKernelGGL(slicer_kernel, dim3(std::max(64, win_blocks / slicer_div)), block, slds, s_, dec, dec_stride, ld16,
+					   n_streams, n_blocks, L, T, lanes_win, head_chunks, kind, 2);
+			mark(m0 + 1, s_);
+			(void)hipStreamWaitEvent(s_, P.ev_coop, 0);
+		} else {
+			if (!(skip & (kind == 0 ? 8 : 4)))
+			hipLaunchKernelGGL(slicer_kernel, dim3(std::max(64, win_blocks / slicer_div)), block, slds, s_, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
+					   lanes_win, head_chunks, kind, 0);
+			mark(m0 + 1, s_);
+			if (!(skip & (kind == 0 ? 2 : 1)))
+			hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L,
+					   T, kind);
+		}
 		mark(m0 + 2, s_);
 		hipLaunchKernelGGL(decode_kernel, dim3(dec_blocks), block, 0, s_, n_streams, L, T, kind);
 		mark(m0 + 3, s_);
@@ -3268,13 +3314,14 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		TRY(hipStreamWaitEvent(P.k2, P.ev_win, 0));
 		if (fm_on_kw) {
 			TRY(hipStreamWaitEvent(P.k2, P.ev_fm, 0));
-		} else if (P.fmdev_wmax > 0) {
+		} else if (P.fmdev_wmax > 0 && !(skip & 64)) {
 			mark(24, P.k2);
 			TRY(launch_fmdev(P.k2, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,
 					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));
 			mark(25, P.k2);
 		}
 		mark(1, P.k2);
+		if (!(skip & 128))
 		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(2, P.k2);
@@ -3285,8 +3332,10 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}
+		if (!(skip & 128))
 		hipLaunchKernelGGL((spec_biquad_kernel<false, 1>), dim3(repair_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
+		if (!(skip & 128))
 		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(repair_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(3, P.k2);

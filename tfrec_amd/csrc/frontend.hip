@@ -375,7 +375,7 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 
 // after the front end (and the auto-threshold pass, which rewrites the mask)
 // Parity probe (tfrec_amd_fm_dev_probe): the device's fm_dev -- fast path, exact slow path and log -- on arbitrary
-// quadruples (kind 0: int32 ar, aj, br, bj) or cross terms (kind 1: int64 cr, cj).
+// quadruples (kind 0: int32 ar, aj, br, bj) or cross terms (kind 1: int64 cr, cj); kind 2: fm_dev_nrzs of quadruples.
 __global__ __launch_bounds__(256) void fm_probe_kernel(const int32_t *__restrict__ quads, size_t n, int32_t *__restrict__ out,
 							 EventBuf *__restrict__ eb, int kind)
 {
@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256) void fm_probe_kernel(const int32_t *__restrict
 	if (kind == 0) {
 		const int4 q = reinterpret_cast<const int4 *>(quads)[k];
 		out[k] = fm_dev(q.x, q.y, q.z, q.w, eb, kAtanPolyFront);
+	} else if (kind == 2) {  // fm_dev_nrzs (dsp_stuff.cpp:269-279) incl. its +-1e9 clamp
+		const int4 q = reinterpret_cast<const int4 *>(quads)[k];
+		out[k] = fm_dev_nrzs(q.x, q.y, q.z, q.w);
 	} else {
 		const longlong2 c = reinterpret_cast<const longlong2 *>(quads)[k];
 		out[k] = fm_dev_cross((double)c.x, (double)c.y, eb, kAtanPolyFront);

@@ -253,6 +253,10 @@ struct PipeCtl {
 	hipEvent_t ev_fork;        // first TFA_2 biquad pass done (k2): TFA_1 starts
 	hipEvent_t ev_k2, ev_kw;   // stage A done
 	hipEvent_t ev_fm;          // the discriminator pass done, when it runs at the head of kw instead of k2
+	// TFA_2 family, stage B split: once the long windows' heads are sliced (cs), the cooperative slicers of their tails
+	// run on cz beside the short windows' slicers on cs (nullptr: one after the other on cs)
+	hipStream_t cz;
+	hipEvent_t ev_heads, ev_coop;
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
 	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
 	// the FM discriminator pass, when it runs at the head of stage A of the TFA_2 family (k2) instead of behind the
@@ -262,7 +266,7 @@ struct PipeCtl {
 	int16_t *fmdev_out;
 	const uint32_t *prevdec;
 };
-constexpr int kTimingMarks = 28;
+constexpr int kTimingMarks = 30;
 
 constexpr int kNQueues = 8;
 // one more counter after the work queues, with a (stream, slot) list behind the queues' items: the TFA_2-family
