@@ -22,6 +22,9 @@ __device__ __forceinline__ void group8(const int32_t *d, double bh, double a1, d
 	unsigned long long cm = 0, co;
 	int iyv[8];
 	unsigned long long cmv[8];
+	double yv[8];
+	if (V == 14 || V == 15)
+		__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
 		const double tt2 = i == 0 ? t2 : (i == 1 ? t1 : t0[i - 2]);
@@ -30,6 +33,7 @@ __device__ __forceinline__ void group8(const int32_t *d, double bh, double a1, d
 		const double s1 = tt2 + m1;
 		const double s2 = s1 + pp[i];
 		const double y = s2 + m2;
+		yv[i] = y;
 		if (V == 0) {  // compare into an SGPR pair, carry into the shift
 			const int iy = (int)y;
 			asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(cm) : "v"(d[i]), "v"(iy));
@@ -72,6 +76,28 @@ __device__ __forceinline__ void group8(const int32_t *d, double bh, double a1, d
 		}
 		yb = ya;
 		ya = y;
+	}
+	if (V == 14 || V == 15) {  // the eight conversions TOGETHER behind the chain (a scheduling barrier keeps them there)
+		__builtin_amdgcn_sched_barrier(0);
+		int iy[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++)
+			iy[i] = (int)yv[i];
+		__builtin_amdgcn_sched_barrier(0);
+		if (V == 14) {
+#pragma unroll
+			for (int i = 0; i < 8; i++)
+				bits += (uint32_t)iy[i];
+		} else {
+#pragma unroll
+			for (int i = 0; i < 8; i++) {
+				asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(cmv[i]) : "v"(d[i]), "v"(iy[i]));
+			}
+#pragma unroll
+			for (int i = 0; i < 8; i++)
+				asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits), "=s"(co) : "s"(cmv[i]));
+		}
+		__builtin_amdgcn_sched_barrier(0);
 	}
 	if (V == 11) {
 #pragma unroll
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(64) void k(const int32_t *in, int reps, double a1, 
 			group8<V>(A[s], bh, a1, a2, y1[s], y2[s], t1[s], t2[s], bits[s]);
 #pragma unroll
 		for (int s = 0; s < NS; s++)
-			A[s][r & 7] += (int)bits[s] & 1;  // keeps the inputs loop-variant
+			A[s][0] += (int)(bits[s] & 1u) + (r & 1);  // keeps the inputs loop-variant (a static index: a dynamic one is a 35-instruction select cascade)
 	}
 	const unsigned long long c1 = __builtin_readcyclecounter();
 	double acc = 0;
@@ -172,6 +198,8 @@ int main()
 	run<8, 1>("+ threshold by pre-pass, one f64 compare -> addc");
 	run<9, 1>("+ one f64 compare -> addc only");
 	run<10, 1>("+ v_trunc_f64 only");
+	run<14, 1>("chain of 8, then the 8 cvt_i32_f64 together (sched_barrier)");
+	run<15, 1>("chain of 8, then 8 cvt, 8 cmp, 8 addc, each kind together");
 	run<11, 1>("cvt per sample, 8 x (cmp -> sgpr -> addc) at the group's end");
 	run<12, 1>("cvt per sample, 8 compares packed in plain C at the group's end");
 	run<13, 1>("f64 compare per sample into 8 sgpr pairs, 8 addc at the group's end");

@@ -49,6 +49,12 @@ static int env_int(const char *name, int dflt, int lo = 0, int hi = 1 << 30)
 
 constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
 
+// tfa1.cpp:159 "mark_lvl = (int)(mark_lvl * 0.95)" for mark_lvl >= 0 (the peak detector never goes negative) without the
+// trip through a double: the double nearest 0.95 is 0.95 - 4.4e-17, so the exact product is m * 19 / 20 minus less than
+// 0.22 ulp of itself -- it rounds back to m * 19 / 20 where that is an integer and stays strictly inside
+// (floor, floor + 1) elsewhere (the fraction is a multiple of 1 / 20): (int) of it is floor(m * 19 / 20) = m - ceil(m / 20).
+__device__ __forceinline__ int tfa1_decay(int m) { return m - (int)(((uint32_t)m + 19u) / 20u); }
+
 // Wave priority of the LATENCY-bound kernels (serial chains per lane or per wave: slicers, WHB stage 2 and its check):
 // experiment knob, see DESIGN.md 7d
 #ifndef TFREC_AMD_LAT_PRIO
@@ -936,7 +942,16 @@ struct Slicer {  // window-local demodulator state (tfa1.h:28-32, tfa2.h:35-42)
 	int mark_lvl, rssi_i;                          // tfa1 (rssi_i also tfa2)
 	int bitcnt, dmin, dmax, offset, last_bit;      // tfa2
 	int first_cand_g;
+	int hi, lo;  // tfa2.cpp:379-381: noffset + dmax / 32, noffset + dmin / 32 -- functions of (offset, dmax, dmin), which only move
+	             // while bitcnt < 10: kept instead of recomputed at every sample (a conversion to double and back, a product
+	             // and two range compares per sample of a loop that runs at a lone wave's issue rate)
 };
+__device__ __forceinline__ void tfa2_thresholds(Slicer &f)
+{
+	const int noffset = d2i(0.9 * f.offset);
+	f.hi = noffset + f.dmax / 32;
+	f.lo = noffset + f.dmin / 32;
+}
 
 __device__ __forceinline__ void slicer_fresh(Slicer &f, int kind)
 {
@@ -948,6 +963,7 @@ __device__ __forceinline__ void slicer_fresh(Slicer &f, int kind)
 	f.offset = 0;
 	f.last_bit = 0;
 	f.first_cand_g = -1;
+	f.hi = f.lo = 0;
 	(void)kind;
 }
 
@@ -965,7 +981,7 @@ __device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int g, int
 	if (dev > f.mark_lvl)
 		f.mark_lvl = dev;
 	else
-		f.mark_lvl = d2i(f.mark_lvl * 0.95);
+		f.mark_lvl = tfa1_decay(f.mark_lvl);
 	if (f.mark_lvl > f.rssi_i)
 		f.rssi_i = f.mark_lvl;
 	if (dev < f.mark_lvl / 2) {
@@ -1004,9 +1020,9 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 			const uint32_t t = (uint32_t)f.rssi_i + (uint32_t)(I * I) + (uint32_t)(Q * Q);
 			f.rssi_i = (int)((uint32_t)f.rssi_i + (uint32_t)((int)t / 100));
 		}
+		tfa2_thresholds(f);
 	}
-	const int noffset = d2i(0.9 * f.offset);
-	const int hi = noffset + f.dmax / 32, lo = noffset + f.dmin / 32;
+	const int hi = f.hi, lo = f.lo;
 	const int bit = ld > hi ? 1 : 0;
 	if ((ld > hi || ld < lo) && bit != f.last_bit) {
 		if (f.first_cand_g < 0)
@@ -1175,6 +1191,8 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	} else {
 		f.lbi = kSpecLbi;  // speculation, validated by commit_kernel
 	}
+	if (KIND == 1)
+		tfa2_thresholds(f);
 	BitWriter bw{ T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0u, 0, 0u, -1 };
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
@@ -1286,7 +1304,7 @@ __global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void mark_kernel(const uint
 				const int I = (int)(int16_t)(A.w[k] & 0xffff), Q = (int)A.w[k] >> 16;
 				if (k < nv) {
 					const int dev = fm_dev_nrzs(I, Q, pI, pQ);
-					mark = dev > mark ? dev : (int)((double)mark * 0.95);  // mark >= 0: plain truncation
+					mark = dev > mark ? dev : tfa1_decay(mark);
 					mx = mark > mx ? mark : mx;
 					bits |= (uint32_t)(dev < mark / 2) << k;
 				}
@@ -1611,7 +1629,7 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 			// the peak detector, wave-uniform (tfa1.cpp:157-160); mark >= 0 always, so (int) truncation is exact
 			for (int k = 0; k < nv; k++) {
 				const int dk = __builtin_amdgcn_readlane(dev, k);
-				mark = dk > mark ? dk : (int)((double)mark * 0.95);
+				mark = dk > mark ? dk : tfa1_decay(mark);
 				lds_m[k] = mark;
 			}
 			__syncthreads();
