@@ -2594,9 +2594,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 // every recorded decision is compared with it: FOUR STREAMS PER WAVE, one per row of 16 lanes.  The chain is serial
 // per stream and costs a wave ~35 cycles per sample whatever its lanes hold (6 fp64 instructions, DPP-broadcast inputs):
 // executed for ONE stream per wave, as the exact demodulator kernel does, it is a third of the batch's vector
-// instructions; a row of 16 lanes is all the broadcast needs.  (A lane per stream looked cheaper still and is not: the
-// conversion "(int)" alone costs a lone wave 38 cycles per instruction, scattered 16-byte accesses of 64 rows ~60 each --
-// profiles/ubench/verify_chain.hip; here both are paid once per 16 samples.)
+// instructions; a row of 16 lanes is all the broadcast needs.  (A lane per stream was tried first: its arithmetic is 45
+// cycles per sample, profiles/ubench/verify_chain.hip, but the flat loop around it -- 16-byte accesses of 64 different rows
+// per instruction, lanes in different groups of a half-step -- ran at 108)
 // The code below is written per lane; the lanes of a row hold the same stream, window and step throughout, so every
 // branch is uniform per row.  Where the decoder locked, the average was frozen as an integer (whb.cpp:653-654): (int) of
 // the speculated double is the exact one's neighbour once in ~200 locks; that is accepted iff no candidate test of the
