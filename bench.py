@@ -434,14 +434,16 @@ def main():
                 vj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_valu.json")))
                 valu = {
                     "insts_per_batch": {k: int(v) for k, v in vj["per_batch"].items()},
-                    "cycles_per_instruction_per_simd": vj["cycles_per_instruction_per_simd"],
-                    "roof_ms": vj["valu_roof_ms"], "salu_roof_ms": vj["salu_roof_ms"],
+                    "ns_per_instruction_per_simd": vj["ns_per_instruction_per_simd"],
+                    "roof_ms": vj["valu_roof_ms"], "busy_ms_counters": vj["valu_busy_ms_counters"],
+                    "salu_roof_ms": vj["salu_roof_ms"], "salu_busy_ms_counters": vj["salu_busy_ms_counters"],
                     "frac": round(vj["valu_roof_ms"] / (elapsed / a.steps * 1e3), 4),
                     "sum_of_kernel_ms_alone": vj["sum_of_kernel_ms_alone"],
                     "how": "VALU wave-instructions of one batch by class (rocprofv3 --pmc, profiles/%s_pmc_mix.txt) x the measured "
-                           "issue cost per class with 8 waves per SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl) "
-                           "/ (1024 SIMDs x 2.4 GHz); frac = that / ms_per_step; per-kernel counter-derived VALU busy: profiles/%s_valu.json"
-                           % (ptag, ptag, ptag),
+                           "time per instruction and SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl: kernel time / "
+                           "(instructions per wave x waves per SIMD), 1.6-2.1 ns = 4 cycles) / 1024 SIMDs; busy_ms_counters = "
+                           "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), the same roof from the counters alone; frac = "
+                           "roof_ms / ms_per_step; per kernel: profiles/%s_valu.json" % (ptag, ptag, ptag),
                 }
             except Exception:
                 pass

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """VALU work of one batch from two rocprofv3 PMC passes (profiles/run_valu.sh) + the measured issue cost per instruction
-class (profiles/ubench/valu_issue.hip, 8 waves per SIMD) -> the VALU-issue roof of bench.py's roofline.valu block.
+class (profiles/ubench/valu_issue.hip) -> the VALU-issue roof of bench.py's roofline.valu block.
 usage: make_valu.py <pmc_valu.txt> <pmc_mix.txt> <valu_issue.jsonl> <out.json>
 
 Per kernel (dispatches are serialised by the counter collection: the kernel's own figures):
   valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)   (SQ_ACTIVE_INST_* count quad-cycles)
 Per batch (one batch = one frontend launch):
-  issue_cycles = sum over classes of instructions x measured cycles per instruction and SIMD with 8 waves per SIMD
-  valu_roof_ms = issue_cycles / (1024 SIMDs x 2.4 GHz)
+  valu_roof_ms = sum over classes of instructions x measured TIME per instruction and SIMD / 1024 SIMDs
+  valu_busy_ms_counters = sum over kernels of SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz): the same roof from
+                          the counters alone (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU within 4 %: four cycles per instruction)
+The time per instruction is the microbenchmark's kernel time / (instructions per wave x waves per SIMD), the minimum over
+2, 4 and 8 waves per SIMD: 1.6-2.1 ns for the floating-point classes = 4 cycles of a 16-lane SIMD at 2.0-2.4 GHz, as the
+data sheet has it.  (Round 3's first version multiplied the benchmark's s_memtime ticks per instruction by 1 / 2.4 GHz.
+With 8 waves per SIMD the waves do not all run at once -- the kernel took twice as long as its slowest wave's ticks --,
+so "1.4-2.6 cycles per instruction" and a roof of 1.79 ms were a factor two too low: the counters said so all along.)
 """
 import json, re, sys
 
@@ -29,17 +35,19 @@ def parse(path):
 
 
 valu, mix = parse(sys.argv[1]), parse(sys.argv[2])
-cost = {}
+cost = {}  # ns per instruction and SIMD
 for ln in open(sys.argv[3]):
     ln = ln.strip()
     if ln.startswith("{"):
         j = json.loads(ln)
-        if j["waves_per_simd"] == 8:
-            cost[j["class"]] = j["cycles_per_inst_per_simd"]
+        if j["waves_per_simd"] >= 2 and "clock_ghz" in j:
+            ns = j["cycles_per_inst_per_simd"] / j["clock_ghz"]  # = kernel time / (instructions per wave x waves per SIMD)
+            cost[j["class"]] = min(cost.get(j["class"], 1e9), round(ns, 3))
 cls_cost = {"fp64": cost["v_fma_f64"], "fma_f32": cost["v_pk_fma_f32"], "cvt": cost["v_cvt_f64_i32"], "int32": cost["v_add_u32"],
             "other": cost["v_fma_f32"], "salu": cost["s_add_u32"]}
 nb = max(d["dispatches"] for n, ds in valu.items() if n.startswith("frontend_kernel") for d in ds)
 kernels = {}
+busy_valu = busy_sca = 0.0
 tot = dict(valu=0.0, fp64=0.0, fma_f32=0.0, cvt=0.0, int32=0.0, other=0.0, salu=0.0)
 for name, ds in valu.items():
     if name.startswith("__"):
@@ -59,14 +67,19 @@ for name, ds in valu.items():
                             fma_f32=f32, cvt=cvt, int32=i32, other=other, kernel_cycles_alone=gui_cycles,
                             kernel_ms_alone=round(gui_cycles / (CLOCK_GHZ * 1e6), 4),
                             valu_busy=round(4.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, gui_cycles * N_SIMD), 4))
+        busy_valu += 4.0 * d.get("SQ_ACTIVE_INST_VALU", 0) * per
+        busy_sca += 4.0 * d.get("SQ_ACTIVE_INST_SCA", 0) * per
         for c, v in (("valu", nv), ("fp64", fp64), ("fma_f32", f32), ("cvt", cvt), ("int32", i32), ("other", other),
                      ("salu", d.get("SQ_INSTS_SALU", 0))):
             tot[c] += v * per
-issue = sum(tot[c] * cls_cost[c] for c in ("fp64", "fma_f32", "cvt", "int32", "other"))
-out = dict(note=__doc__.strip(), cycles_per_instruction_per_simd=cls_cost, per_batch=tot, valu_issue_cycles_per_batch=issue,
-           valu_roof_ms=round(issue / (N_SIMD * CLOCK_GHZ * 1e6), 4),
-           salu_roof_ms=round(tot["salu"] * cls_cost["salu"] / (N_SIMD * CLOCK_GHZ * 1e6), 4),
+issue = sum(tot[c] * cls_cost[c] for c in ("fp64", "fma_f32", "cvt", "int32", "other"))  # SIMD-ns
+out = dict(note=__doc__.strip(), ns_per_instruction_per_simd=cls_cost, per_batch=tot, valu_issue_simd_ns_per_batch=issue,
+           valu_roof_ms=round(issue / N_SIMD / 1e6, 4),
+           valu_busy_ms_counters=round(busy_valu / (N_SIMD * CLOCK_GHZ * 1e6), 4),
+           salu_roof_ms=round(tot["salu"] * cls_cost["salu"] / N_SIMD / 1e6, 4),
+           salu_busy_ms_counters=round(busy_sca / (N_SIMD * CLOCK_GHZ * 1e6), 4),
            sum_of_kernel_ms_alone=round(sum(k["kernel_ms_alone"] * k["launches_per_batch"] for k in kernels.values()), 3),
            kernels=kernels)
 json.dump(out, open(sys.argv[4], "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("per_batch", "valu_roof_ms", "salu_roof_ms", "sum_of_kernel_ms_alone")}, indent=1))
+print(json.dumps({k: out[k] for k in ("per_batch", "ns_per_instruction_per_simd", "valu_roof_ms", "valu_busy_ms_counters",
+                                      "salu_roof_ms", "salu_busy_ms_counters", "sum_of_kernel_ms_alone")}, indent=1))

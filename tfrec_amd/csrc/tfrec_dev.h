@@ -17,8 +17,11 @@ constexpr int kTailBytes = 112;                 // raw bytes of history carried 
 constexpr int kNSlots = TFREC_AMD_NSLOTS;
 
 // ---- front-end tile geometry
-constexpr int kTileDec = 1024;                       // decimated outputs per workgroup tile
-constexpr int kFrontThreads = 256;
+#ifndef TFREC_AMD_TILE
+#define TFREC_AMD_TILE 1024
+#endif
+constexpr int kTileDec = TFREC_AMD_TILE;             // decimated outputs per workgroup tile (a multiple of 256)
+constexpr int kFrontThreads = kTileDec / 4;          // four outputs per thread
 constexpr int kRawChunks = (kTailBytes + 8 * kTileDec + 16 + 15) / 16;  // 16-byte chunks staged per tile
 constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per channel (need 2*T+24)
 
