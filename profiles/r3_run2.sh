@@ -1,5 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8) > gpurun_out/r3b_pytest.txt
-timeout 300 profiles/ubench/valu_issue > gpurun_out/r3b_valu_issue.jsonl 2> gpurun_out/r3b_valu_issue.err; echo "rc=$?" >> gpurun_out/r3b_valu_issue.err
-cat gpurun_out/r3b_pytest.txt; cat gpurun_out/r3b_valu_issue.err; cat gpurun_out/r3b_valu_issue.jsonl
+B="--steps 60 --warmup 5 --cpu-budget 0 --h2d-steps 0 --parity-streams 64 --no-extra-configs"
+for r in 1 2; do python bench.py $B 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1])
+k=j['roofline']['kernels_ms']
+print('run', j['ms_per_step'], j['ms_per_step_steady'], j['config']['parity_ok'], ' '.join('%s=%.2f'%(a.replace('_kernel',''),b) for a,b in sorted(k.items(), key=lambda kv:-kv[1]) if b>0.3))
+"; done
+rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk" | head -4

@@ -1,3 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 profiles/run_steps.sh r3o > /dev/null 2>&1
-tail -2 gpurun_out/r3o_steps.txt
+mkdir -p gpurun_out
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > gpurun_out/r3p_pytest.txt
+cat gpurun_out/r3p_pytest.txt
+B="--steps 60 --warmup 5 --cpu-budget 0 --h2d-steps 0 --parity-streams 64 --no-extra-configs"
+for lib in "" tfrec_amd/ab_l2.so "" tfrec_amd/ab_l2.so; do
+if [ -n "$lib" ]; then export TFREC_AMD_LIB=$PWD/$lib; else unset TFREC_AMD_LIB; fi
+TFREC_AMD_SHORT_TAILS=0 python bench.py $B 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1])
+k=j['roofline']['kernels_ms']
+print('lib [$lib]', j['ms_per_step'], j['ms_per_step_steady'], j['config']['parity_ok'], ' '.join('%s=%.2f'%(a.replace('_kernel',''),b) for a,b in sorted(k.items(), key=lambda kv:-kv[1]) if b>0.3))
+"; done

@@ -605,7 +605,14 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	int prio_lo = 0, prio_hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
 	const int prio_fs = getenv("TFREC_AMD_PRIO_FS") ? atoi(getenv("TFREC_AMD_PRIO_FS")) : prio_hi;
-	(void)prio_lo;
+	// (experiments: TFREC_AMD_PRIO = one letter h / n / l per stream in the order fs cp cs t1 aux k2 kw, default "hnhhhnn")
+	const char *prio_env = getenv("TFREC_AMD_PRIO");
+	auto prio_of = [&](int k, int dflt) {
+		if (!prio_env || strlen(prio_env) <= (size_t)k)
+			return dflt;
+		return prio_env[k] == 'h' ? prio_hi : (prio_env[k] == 'l' ? prio_lo : 0);
+	};
+	auto mkstream = [&](hipStream_t *st, int k, int dflt) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(k, dflt)); };
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb;
@@ -617,9 +624,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    (c->in10x && (hipMemset(c->d_tail10[0], 0x80, n * 112) != hipSuccess ||
 				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
-		    hipStreamCreateWithPriority(&c->fs, hipStreamNonBlocking, prio_fs) != hipSuccess ||
-		    hipStreamCreateWithFlags(&c->cp, hipStreamNonBlocking) != hipSuccess ||
-		    hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+		    mkstream(&c->fs, 0, prio_fs) != hipSuccess ||
+		    mkstream(&c->cp, 1, 0) != hipSuccess ||
+		    mkstream(&c->cs, 2, prio_hi) != hipSuccess ||
 		    false)
 			rc = TFREC_AMD_E_HIP;
 		for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++) {
@@ -636,8 +643,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		}
 	}
 	if (rc == TFREC_AMD_OK && !(cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)) {
-		if (hipStreamCreateWithPriority(&c->t1, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-		    hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
+		if (mkstream(&c->t1, 3, prio_hi) != hipSuccess || mkstream(&c->aux, 4, prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 		// deep layout (default; TFREC_AMD_DEEP=0 selects the shallow one): the biquad stages get streams of their own
 		const char *dp = getenv("TFREC_AMD_DEEP");
@@ -654,8 +660,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		c->kw = c->aux;
 		c->vx = c->aux;
 		if (c->deep && rc == TFREC_AMD_OK &&
-		    (hipStreamCreateWithFlags(&c->k2, hipStreamNonBlocking) != hipSuccess ||
-		     hipStreamCreateWithFlags(&c->kw, hipStreamNonBlocking) != hipSuccess))
+		    (mkstream(&c->k2, 5, 0) != hipSuccess || mkstream(&c->kw, 6, 0) != hipSuccess))
 			rc = TFREC_AMD_E_HIP;
 		// TFREC_AMD_COOP_STREAM=1: a stream for the TFA_2 family's cooperative slicers (PipeCtl::cz).  It is the fifth of high
 		// priority: with the HIP default of four hardware queues per priority it shares one (GPU_MAX_HW_QUEUES >= 8 wanted).
@@ -734,6 +739,11 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		fin = (const uint8_t *)c->d_in16[set];
 		fstride = c->in16_stride * sizeof(uint32_t);
 	}
+	// (TFREC_AMD_SKIP bit 512, WHAT-IF timing only: after the first 12 submits the front end is left out and the chains run
+	// on what the buffer set holds from four submits ago -- what the front end costs the batch period)
+	static const bool whatif_no_fe = getenv("TFREC_AMD_SKIP") && (atoi(getenv("TFREC_AMD_SKIP")) & 512);
+	static int whatif_submits = 0;
+	if (!(whatif_no_fe && ++whatif_submits > 12))
 	HIPCHK(launch_frontend(fs, fin, fstride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
 			       c->d_tail[c->tail_sel ^ 1], c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride,
 			       c->d_prevdec[set], c->cfg.thresh ? c->cfg.thresh : 500, c->taps, c->in10x));
@@ -790,6 +800,38 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		HIPCHK(launch_pipeline(P, c->d_dec[set], c->dec_stride, c->d_mask[set], c->mask_stride, c->d_fmdev[set], c->dec_stride,
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
 				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
+	}
+	if (getenv("TFREC_AMD_DEBUG_WINHIST") && c->submit_seq == 3) {  // (debug: the window length distribution of one submit)
+		(void)hipDeviceSynchronize();
+		const WinTables &T = c->win[set];
+		const size_t chains = (size_t)c->launch.n_active * c->cfg.n_streams;
+		std::vector<int32_t> cnt(chains), op(chains * T.cap), cl(chains * T.cap);
+		(void)hipMemcpy(cnt.data(), T.count, chains * 4, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(op.data(), T.open, chains * T.cap * 4, hipMemcpyDeviceToHost);
+		(void)hipMemcpy(cl.data(), T.close, chains * T.cap * 4, hipMemcpyDeviceToHost);
+		const int M = n_blocks * kBlockDec;
+		for (int a = 0; a < c->launch.n_active; a++) {
+			long hist[16] = { 0 }, nwin = 0, tot = 0;
+			for (int s = 0; s < c->cfg.n_streams; s++) {
+				const size_t ch = (size_t)a * c->cfg.n_streams + s;
+				for (int j = 0; j < cnt[ch]; j++) {
+					const int last = cl[ch * T.cap + j] < M ? cl[ch * T.cap + j] : M - 1;
+					const int n = last - op[ch * T.cap + j] + 1;
+					int b = 0;
+					while ((256 << b) <= n && b < 15)
+						b++;
+					hist[b]++;
+					nwin++;
+					tot += n;
+				}
+			}
+			fprintf(stderr, "WINHIST slot %d kind %d window %d: %ld windows, %ld samples (%.1f %% of the submit);", a, c->launch.params[a].kind,
+				c->launch.params[a].window, nwin, tot, 100.0 * tot / ((double)M * c->cfg.n_streams));
+			for (int b = 0; b < 16; b++)
+				if (hist[b])
+					fprintf(stderr, " <%d:%ld", 256 << b, hist[b]);
+			fprintf(stderr, "\n");
+		}
 	}
 	// the drain's copies, queued now
 	for (auto &e : c->done[set])

@@ -100,6 +100,22 @@ struct BitWriter {
 			acc = 0;
 		}
 	}
+	// cnt in [1, 31] bits at once, bit k of v = the k-th of them (the run of an accepted edge: tfa2.cpp:399-404)
+	__device__ __forceinline__ void put_bits(uint32_t v, int cnt)
+	{
+		const int sh = n & 31;
+		const unsigned long long a = (unsigned long long)acc | ((unsigned long long)v << sh);
+		n += cnt;
+		if (sh + cnt >= 32) {
+			if (pend_idx >= 0)
+				base[pend_idx] = pend;
+			pend = (uint32_t)a;
+			pend_idx = (n >> 5) - 1;
+			acc = (uint32_t)(a >> 32);
+		} else {
+			acc = (uint32_t)a;
+		}
+	}
 	__device__ __forceinline__ void chunk_end()
 	{
 		const int idx = pend_idx >= 0 ? pend_idx : (n >> 5);
@@ -942,6 +958,7 @@ struct Slicer {  // window-local demodulator state (tfa1.h:28-32, tfa2.h:35-42)
 	int mark_lvl, rssi_i;                          // tfa1 (rssi_i also tfa2)
 	int bitcnt, dmin, dmax, offset, last_bit;      // tfa2
 	int first_cand_g;
+	int td_lo, td_hi;  // tfa2.cpp:393 "tdiff > spb / 4 && tdiff < 32 * spb" for the integer tdiff: td_lo <= tdiff <= td_hi
 	int hi, lo;  // tfa2.cpp:379-381: noffset + dmax / 32, noffset + dmin / 32 -- functions of (offset, dmax, dmin), which only move
 	             // while bitcnt < 10: kept instead of recomputed at every sample (a conversion to double and back, a product
 	             // and two range compares per sample of a loop that runs at a lone wave's issue rate)
@@ -998,6 +1015,28 @@ __device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int g, int
 	}
 }
 
+// A candidate edge at sample g (tfa2.cpp:383-411: outside the dead band, bit != last_bit): glitch rule, edge timing, the
+// bits it emits, last_bit_idx.  (The caller has brought last_bit_idx to g's block.)
+__device__ __forceinline__ void tfa2_candidate(Slicer &f, BitWriter &bw, int g, int bit, double spb, uint64_t nb_mul)
+{
+	const int index = 2 * (g & (kBlockDec - 1));
+	if (f.first_cand_g < 0)
+		f.first_cand_g = g;
+	if (index > f.lbi + 8) {
+		f.bitcnt++;
+		const int tdiff = index - f.lbi;
+		if (tdiff >= f.td_lo && tdiff <= f.td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
+			const int numbits = nb_mul ? tfa2_numbits_mul(tdiff, nb_mul) : d2i(((tdiff / 2) + (spb / 2)) / spb);
+			// numbits - 1 copies of last_bit (none if numbits >= 32: tfa2.cpp:400), then the new bit: one append
+			const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
+			bw.put_bits((f.last_bit ? (1u << run) - 1u : 0u) | ((uint32_t)bit << run), run + 1);
+			f.last_bit = bit;
+		}
+	}
+	if (index - f.lbi > 2)
+		f.lbi = index;
+}
+
 // One sample of tfa2_demod::demod inside a window (tfa2.cpp:357-412), ld = (int)iir->step(fm_dev(...)).
 __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int ld, const uint32_t *drow, double spb,
 					    uint64_t nb_mul)
@@ -1007,41 +1046,27 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 		f.lbi = rebase_lbi(f.lbi, f.cur_block, b);
 		f.cur_block = b;
 	}
-	const int index = 2 * (g & (kBlockDec - 1));
 	if (f.bitcnt < 10) {
-		if (ld > f.dmax)
+		const bool up = ld > f.dmax, down = ld < f.dmin;
+		if (up)
 			f.dmax = (7 * f.dmax + ld) / 8;
-		if (ld < f.dmin)
+		if (down)
 			f.dmin = (7 * f.dmin + ld) / 8;
-		f.offset = (f.dmax + f.dmin) / 2;
+		if (up || down) {  // offset and the thresholds are functions of (dmax, dmin): tfa2.cpp:369, 379-381
+			f.offset = (f.dmax + f.dmin) / 2;
+			tfa2_thresholds(f);
+		}
 		if (f.bitcnt > 4) {  // wrapping int32 arithmetic as in the reference binary (tfa2.cpp:373)
 			const uint32_t cw = drow[g];
 			const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
 			const uint32_t t = (uint32_t)f.rssi_i + (uint32_t)(I * I) + (uint32_t)(Q * Q);
 			f.rssi_i = (int)((uint32_t)f.rssi_i + (uint32_t)((int)t / 100));
 		}
-		tfa2_thresholds(f);
 	}
 	const int hi = f.hi, lo = f.lo;
 	const int bit = ld > hi ? 1 : 0;
-	if ((ld > hi || ld < lo) && bit != f.last_bit) {
-		if (f.first_cand_g < 0)
-			f.first_cand_g = g;
-		if (index > f.lbi + 8) {
-			f.bitcnt++;
-			const int tdiff = index - f.lbi;
-			if (tdiff > spb / 4 && tdiff < 32 * spb) {
-				const int numbits = nb_mul ? tfa2_numbits_mul(tdiff, nb_mul) : d2i(((tdiff / 2) + (spb / 2)) / spb);
-				if (numbits < 32)
-					for (int n = 1; n < numbits; n++)
-						bw.put(f.last_bit);
-				bw.put(bit);
-				f.last_bit = bit;
-			}
-		}
-		if (index - f.lbi > 2)
-			f.lbi = index;
-	}
+	if ((ld > hi || ld < lo) && bit != f.last_bit)
+		tfa2_candidate(f, bw, g, bit, spb, nb_mul);
 }
 
 // Run one window [g0, last] of a TFA_1 (KIND 0) or TFA_2-family (KIND 1) slicer.  `f` carries the state in and
@@ -1191,8 +1216,11 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	} else {
 		f.lbi = kSpecLbi;  // speculation, validated by commit_kernel
 	}
-	if (KIND == 1)
+	if (KIND == 1) {
 		tfa2_thresholds(f);
+		f.td_lo = (int)floor(p.spb / 4) + 1;
+		f.td_hi = (int)ceil(32 * p.spb) - 1;
+	}
 	BitWriter bw{ T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0u, 0, 0u, -1 };
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +

@@ -122,17 +122,26 @@ __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out,
 	const double kPi = 0x1.921fb54442d18p+1, kPi2 = 0x1.921fb54442d18p+0, kPi4 = 0x1.921fb54442d18p-1,
 		     k3Pi4 = 0x1.2d97c7f3321d2p+1;
 	double ang;
-	bool generic = false;
-	if (cj == 0.0) {
-		const bool pos = cr > 0.0 || (cr == 0.0 && !signbit(cr));
-		ang = copysign(pos ? 0.0 : kPi, cj);
-	} else if (cr == 0.0) {
-		ang = copysign(kPi2, cj);
-	} else if (fabs(cj) == fabs(cr)) {
-		ang = copysign(cr > 0.0 ? kPi4 : k3Pi4, cj);
+	bool generic = true;
+	// The exactly representable directions are a handful of samples per batch: ONE wave-uniform test keeps the four-way
+	// divergent chain of cases (a dozen exec-mask instructions per sample, a third of the discriminator pass's scalar
+	// instructions) out of the samples' common path.
+	const bool special = cj == 0.0 || cr == 0.0 || fabs(cj) == fabs(cr);
+	if (__builtin_expect(__ballot(special) != 0ull, 0)) {
+		generic = false;
+		if (cj == 0.0) {
+			const bool pos = cr > 0.0 || (cr == 0.0 && !signbit(cr));
+			ang = copysign(pos ? 0.0 : kPi, cj);
+		} else if (cr == 0.0) {
+			ang = copysign(kPi2, cj);
+		} else if (fabs(cj) == fabs(cr)) {
+			ang = copysign(cr > 0.0 ? kPi4 : k3Pi4, cj);
+		} else {
+			ang = atan2_int(cj, cr, atan_poly);
+			generic = true;
+		}
 	} else {
 		ang = atan2_int(cj, cr, atan_poly);
-		generic = true;
 	}
 	const double v = ang * kFmScale;
 	*v_out = v;

@@ -253,20 +253,25 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 	const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
 	int pI = (int)(int16_t)(pw & 0xffff), pQ = (int)pw >> 16;
 	int dv[4];
+	bool unc[4];
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
 		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
 		double v;
-		const bool unc = fm_dev_fast(((double)I) * pI + ((double)Q) * pQ, ((double)Q) * pI - ((double)I) * pQ, &v, kAtanPolyFront,
-					     flag_eps);
+		unc[o] = fm_dev_fast(((double)I) * pI + ((double)Q) * pQ, ((double)Q) * pI - ((double)I) * pQ, &v, kAtanPolyFront, flag_eps);
 		dv[o] = d2i(v);
-		if (__builtin_expect(unc, 0)) {  // next to a truncation boundary (~2e-9 of the samples): fm_resolve_kernel decides it
-			const uint32_t i = atomicAdd(&eb->fm_pending, 1u);
-			if (i < (uint32_t)kFmListCap)
-				eb->fm_list[i] = ((unsigned long long)(uint32_t)s << 32) | (uint32_t)(m0 + 4 * tid + o);
-		}
 		pI = I;
 		pQ = Q;
+	}
+	// next to a truncation boundary (~2e-9 of the samples): fm_resolve_kernel decides it (one test for the lane's four samples)
+	if (__builtin_expect(unc[0] || unc[1] || unc[2] || unc[3], 0)) {
+#pragma unroll
+		for (int o = 0; o < 4; o++)
+			if (unc[o]) {
+				const uint32_t i = atomicAdd(&eb->fm_pending, 1u);
+				if (i < (uint32_t)kFmListCap)
+					eb->fm_list[i] = ((unsigned long long)(uint32_t)s << 32) | (uint32_t)(m0 + 4 * tid + o);
+			}
 	}
 	*reinterpret_cast<uint2 *>(fmdev + (size_t)s * fmdev_stride + m0 + 4 * tid) =
 		make_uint2(((uint32_t)dv[0] & 0xffffu) | ((uint32_t)dv[1] << 16), ((uint32_t)dv[2] & 0xffffu) | ((uint32_t)dv[3] << 16));
