@@ -1395,6 +1395,19 @@ struct CoopBits {
 			}
 		}
 	}
+	// cnt in [1, 32] bits at once, bit k of v = the k-th of them
+	__device__ __forceinline__ void put_bits(uint32_t v, int cnt)
+	{
+		acc |= (unsigned long long)v << nacc;  // nacc < 32 here
+		nacc += cnt;
+		n += cnt;
+		if (nacc >= 32) {
+			if (threadIdx.x == 0)
+				base[(n - nacc) >> 5] = (uint32_t)acc;
+			acc >>= 32;
+			nacc -= 32;
+		}
+	}
 	__device__ __forceinline__ void finish()
 	{
 		if (nacc && threadIdx.x == 0)
@@ -1440,8 +1453,8 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	int cur_block = fresh ? og >> 13 : (g1 - 1) >> 13;
 	int lbi = r0.lbi_out;  // relative to cur_block (run_window leaves it relative to the block of its last sample)
 	// integer form of "tdiff > spb / 4 && tdiff < 32 * spb" (tdiff is an integer)
-	const int td_lo = (int)floor(spb / 4) + 1;
-	const int td_hi = (int)ceil(32 * spb) - 1;
+	const int td_lo = __builtin_amdgcn_readfirstlane((int)floor(spb / 4) + 1);  // (scalars: the walk below is scalar code)
+	const int td_hi = __builtin_amdgcn_readfirstlane((int)ceil(32 * spb) - 1);
 	int hi = 0, lo = 0;
 	auto thresholds = [&]() {  // tfa2.cpp:379-381
 		const int noffset = d2i(0.9 * offset);
@@ -1475,28 +1488,94 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		if (index - lbi > 2)
 			lbi = index;
 	};
-	struct In {
-		int ld;
-		uint32_t iq;
+	// FOUR steps' samples per load: lane l fetches samples l, 64 + l, 128 + l, 192 + l of a 256-sample stretch, the next
+	// stretch's loads are issued before this one is walked.  (One step per load, its value converted where it was loaded,
+	// made the wave wait out the load's full latency in EVERY step: 3500 cycles per 64-sample step for ~110 instructions
+	// of work, and the longest window's 1024 steps set the kernel's time.)  The power (tfa2.cpp:371-375) is only looked at
+	// while the thresholds adapt -- a head that gave up, or commit's exact re-slice: loaded where it is used.
+	struct In4 {
+		uint32_t l0, l1, l2, l3;  // the int16 values as loaded, zero-extended: converting (or packing) them here would be the loads' first use
 	};
-	auto load = [&](int gb) -> In {
-		In v;
-		const int g = gb + lane <= last ? gb + lane : last;
-		v.ld = (int)ldrow[g - og];
-		v.iq = bitcnt < 10 ? drow[g] : 0u;  // only the adaptive phase looks at the power (tfa2.cpp:371-375)
+	auto load4 = [&](int gb4) -> In4 {
+		In4 v;
+		const int g0_ = gb4 + lane, g1_ = g0_ + 64, g2_ = g0_ + 128, g3_ = g0_ + 192;
+		const uint16_t *lu = reinterpret_cast<const uint16_t *>(ldrow);
+		v.l0 = lu[(g0_ <= last ? g0_ : last) - og];
+		v.l1 = lu[(g1_ <= last ? g1_ : last) - og];
+		v.l2 = lu[(g2_ <= last ? g2_ : last) - og];
+		v.l3 = lu[(g3_ <= last ? g3_ : last) - og];
 		return v;
 	};
-	In nxt = load(g1);
-	for (int gb = g1; gb <= last; gb += 64) {
-		const In cur = nxt;
-		if (gb + 64 <= last)
-			nxt = load(gb + 64);
+	In4 nxt4 = load4(g1);
+	for (int gb4 = g1; gb4 <= last; gb4 += 256) {
+	const In4 cur4 = nxt4;
+	if (gb4 + 256 <= last)
+		nxt4 = load4(gb4 + 256);
+#pragma unroll 1
+	for (int q4 = 0; q4 < 4; q4++) {
+		const int gb = gb4 + 64 * q4;
+		if (gb > last)
+			break;
+		struct {
+			int ld;
+			uint32_t iq;
+		} cur;
+		cur.ld = (int)(int16_t)(q4 == 0 ? cur4.l0 : (q4 == 1 ? cur4.l1 : (q4 == 2 ? cur4.l2 : cur4.l3)));
+		cur.iq = bitcnt < 10 ? drow[gb + lane <= last ? gb + lane : last] : 0u;
 		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
 		const bool valid = lane < nv;
 		const int ld = cur.ld;
 		if (bitcnt >= 10) {  // thresholds frozen: two ballots, then only the edges of the polarity that can flip last_bit
 			const unsigned long long m1 = __ballot(valid && ld > hi);
 			const unsigned long long m0 = __ballot(valid && ld < lo) & ~m1;
+			const int o = gb & (kBlockDec - 1);
+			if (nb_mul && o + nv <= kBlockDec) {
+				// The step lies in ONE block (all but one in 128): last_bit_idx is brought to that block once, and the walk over
+				// the candidates is plain scalar arithmetic on indices relative to the step -- an accepted edge appends its
+				// numbits - 1 copies of last_bit and the new bit in one go (tfa2.cpp:399-404).  Same rules as the general walk
+				// below, which keeps the steps that straddle a block boundary (and contexts without the numbits multiplier).
+				const int b = gb >> 13;
+				if (b != cur_block) {
+					lbi = rebase_lbi(lbi, cur_block, b);
+					cur_block = b;
+				}
+				const int ibase = 2 * o;
+				unsigned long long todo = ~0ull;  // positions not yet visited
+				while (true) {
+					const unsigned long long m = (last_bit ? m0 : m1) & todo;
+					if (!m)
+						break;
+					const int k = __builtin_ctzll(m);
+					todo = ~1ull << k;
+					const int index = ibase + 2 * k, d = index - lbi;
+					if (first_cand_g < 0)
+						first_cand_g = gb + k;
+					if (d > 2)
+						lbi = index;  // tfa2.cpp:410-411 (d was taken first: the edge's timing uses the old value)
+					if (d > 8) {          // tfa2.cpp:391
+						bitcnt++;
+						if (d >= td_lo && d <= td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
+							const int numbits = tfa2_numbits_mul(d, nb_mul);
+							const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
+							bw.put_bits((last_bit ? (1u << run) - 1u : 0u) | ((uint32_t)(last_bit ^ 1) << run), run + 1);
+							last_bit ^= 1;
+							continue;
+						}
+					}
+					// not accepted: the run of candidates of the same polarity right behind it cannot be either (see below); it
+					// only moves last_bit_idx, to the last sample at which "index - lbi > 2" fired
+					const unsigned long long rest = m >> 1 >> k;
+					const int R = __builtin_ctzll(~rest);  // candidates at k + 1 .. k + R (rest has zeros at its top)
+					if (R > 0) {
+						const int e = index + 2 - lbi;  // index - lbi at sample k + 1 (<= 4)
+						const int t_set = e > 2 ? 1 : ((2 - e) >> 1) + 2;
+						if (t_set <= R)
+							lbi = index + 2 * (t_set + 2 * ((R - t_set) >> 1));
+						todo = ~1ull << (k + R);
+					}
+				}
+				continue;
+			}
 			unsigned long long todo = ~0ull;  // positions not yet visited
 			while (true) {
 				const unsigned long long m = (last_bit ? m0 : m1) & todo;
@@ -1572,6 +1651,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 			}
 			pos = ke + 1;
 		}
+	}
 	}
 	const int bl = last >> 13;
 	if (bl != cur_block) {
