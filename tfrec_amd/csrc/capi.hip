@@ -72,7 +72,6 @@ struct tfrec_amd_ctx {
 	// HIP multiplexes the streams of one priority onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams
 	// that share a queue serialise (profiles/ubench/queues.hip).  The deep layout (stage A of submit k+1 beside stage B
 	// of submit k) has six streams in two priority classes (see cp below); the shallow one has k2 = cs and kw = aux.
-	hipStream_t lq = nullptr, cq = nullptr;       // TFREC_AMD_VX: a low-priority stream; the stream of the drain's copies if not cp
 	hipStream_t fs = nullptr;                     // front-end stream + window scan (+ the drain's device-to-host copies)
 	hipStream_t cs = nullptr;                     // TFA_2-family slicers and decoders (the caller's stream only orders the input)
 	hipStream_t k2 = nullptr, kw = nullptr;       // biquad stages (deep layout only: else aliases of cs / aux)
@@ -288,8 +287,6 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipStreamDestroy(c->fs);
 	if (c->cp)
 		(void)hipStreamDestroy(c->cp);
-	if (c->lq)
-		(void)hipStreamDestroy(c->lq);
 	if (c->cs)
 		(void)hipStreamDestroy(c->cs);
 	for (int k = 0; k < kSets; k++) {
@@ -675,18 +672,6 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		// hardware queue with kw, and the 6 ms verification of submit k held up the WHB biquads of submit k + 2.
 		if (c->deep)
 			c->vx = c->cp;
-		// TFREC_AMD_VX (experiment): on cp the check of submit k + 1 queues behind the copies of submit k, which wait for ALL chains
-		// of k.  1: the check on a stream of its own, low priority (the low-priority pool's hardware queues are unused); 2: the copies
-		// on such a stream, the check alone on cp.
-		const int vxmode = getenv("TFREC_AMD_VX") ? atoi(getenv("TFREC_AMD_VX")) : 0;
-		if (c->deep && vxmode && rc == TFREC_AMD_OK) {
-			if (hipStreamCreateWithPriority(&c->lq, hipStreamNonBlocking, prio_lo) != hipSuccess)
-				rc = TFREC_AMD_E_HIP;
-			else if (vxmode == 1)
-				c->vx = c->lq;
-			else
-				c->cq = c->lq;
-		}
 		for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++)
 			if (hipEventCreateWithFlags(&c->ev_aux[k], hipEventDisableTiming) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
@@ -849,7 +834,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		}
 	}
 	// the drain's copies, queued now
-	hipStream_t cpy = c->cq ? c->cq : c->cp;
+	hipStream_t cpy = c->cp;
 	for (auto &e : c->done[set])
 		HIPCHK(hipStreamWaitEvent(cpy, e, 0));
 	HIPCHK(hipMemcpyAsync(c->h_eb[set], c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, cpy));
@@ -938,7 +923,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->aux, c->vx, c->t1, c->cp, c->lq })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;

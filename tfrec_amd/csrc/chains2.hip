@@ -1038,8 +1038,8 @@ __device__ __forceinline__ void tfa2_candidate(Slicer &f, BitWriter &bw, int g, 
 }
 
 // One sample of tfa2_demod::demod inside a window (tfa2.cpp:357-412), ld = (int)iir->step(fm_dev(...)).
-__device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int ld, const uint32_t *drow, double spb,
-					    uint64_t nb_mul)
+// iq: the decimated sample itself (looked at while 4 < bitcnt < 10 only: tfa2.cpp:371-375)
+__device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int ld, uint32_t iq, double spb, uint64_t nb_mul)
 {
 	const int b = g >> 13;
 	if (b != f.cur_block) {
@@ -1057,8 +1057,7 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 			tfa2_thresholds(f);
 		}
 		if (f.bitcnt > 4) {  // wrapping int32 arithmetic as in the reference binary (tfa2.cpp:373)
-			const uint32_t cw = drow[g];
-			const int I = (int)(int16_t)(cw & 0xffff), Q = (int)cw >> 16;
+			const int I = (int)(int16_t)(iq & 0xffff), Q = (int)iq >> 16;
 			const uint32_t t = (uint32_t)f.rssi_i + (uint32_t)(I * I) + (uint32_t)(Q * Q);
 			f.rssi_i = (int)((uint32_t)f.rssi_i + (uint32_t)((int)t / 100));
 		}
@@ -1160,7 +1159,11 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 				for (int t = 0; t < 8; t++) {
 					if (8 * q + t < nv) {
 						const int ld = (int)(int16_t)((vw[t >> 1] >> (16 * (t & 1))) & 0xffff);
-						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, drow, spb, nb_mul);
+						// sample 8 q + t of the chunk: group 2 q + (t >> 2) of four, component t & 3
+						// (the sample itself is looked at while 4 < bitcnt < 10 only: tfa2.cpp:371-375.  Staging the chunk's 32 samples in
+						// LDS instead of this load-and-wait made the slicers 20 % faster and the batch 3 % slower: DESIGN.md 7d)
+						const uint32_t iq = (f.bitcnt > 4 && f.bitcnt < 10) ? drow[g0 + kChunk * i + 8 * q + t] : 0u;
+						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, iq, spb, nb_mul);
 					}
 				}
 			}
@@ -2228,7 +2231,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 #endif
 	constexpr int kStep = 64;  // samples per iteration: one per lane
 	const int ln = threadIdx.x;
-	const int s = blockIdx.x;  // one wave per stream
+	// one wave per stream (the body returns where the stream has nothing more to do)
+	auto stream_body = [&](const int s) {
 	uint8_t *const rdata_wave = rdata_lds;
 	const int c = a * n_streams + s;
 	const int M = n_blocks * kBlockDec;
@@ -2688,6 +2692,23 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			__threadfence();
 			atomicAdd(&T.whbgen[s], 1u);
 			atomicAdd(&T.stats[6], 1ull);
+		}
+	}
+	};
+	if (!REDO) {
+		stream_body((int)blockIdx.x);
+	} else {
+		// The redo launch: a handful of workgroups look through the streams' flags, 64 at a time, and redo the failed ones
+		// one after the other (normally none).  As a workgroup per stream it was 1024 waves of 256 registers that had to
+		// find half a SIMD each just to return: 1.2 ms per batch on the stream that sets the period.
+		for (int base = 64 * (int)blockIdx.x; base < n_streams; base += 64 * (int)gridDim.x) {
+			unsigned long long m = __ballot(base + ln < n_streams && T.whbfail[base + ln] != 0);
+			while (m) {
+				const int k = __builtin_ctzll(m);
+				m &= m - 1;
+				stream_body(base + k);
+				__syncthreads();
+			}
 		}
 	}
 }
@@ -3379,7 +3400,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 3) / 4), block, 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
 				   T, P.whb_carry);
 		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly
-		hipLaunchKernelGGL((whb_demod_kernel<true, true>), dim3(n_streams), block, 64 * 64, P.vx, dec, dec_stride, dev32, n_streams,
+		hipLaunchKernelGGL((whb_demod_kernel<true, true>), dim3((n_streams + 63) / 64), block, 64 * 64, P.vx, dec, dec_stride, dev32, n_streams,
 				   n_blocks, sample_base, L, whb_verify, T, events, eb, flags);
 		mark(27, P.vx);
 		TRY(hipEventRecord(P.done[1], P.vx));
