@@ -522,7 +522,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
 		const size_t o_dcd = carve(wins * sizeof(WinDecode)), o_wst = carve(whb ? n * (size_t)T.cap * sizeof(WhbStart) : 0);
 		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve((kNQueues * wins + chains) * sizeof(uint2));
-		const size_t o_queue = carve((kNQueues + 1) * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(64);
+		const size_t o_queue = carve((kNQueues + 1) * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(128);
 		T.segcap = (int32_t)((m_max / 32 + (size_t)T.cap) / kSegSlots + 2);
 		const size_t segs = chains * (size_t)T.segcap;
 		const size_t o_ckpt = carve(chains * (size_t)T.slots * sizeof(double2));
@@ -572,7 +572,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.timeout_carry = c->d_tcarry;
 			T.prevdec = c->d_prevdec[set];
 			if (hipMemset(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
-			    hipMemset(T.stats, 0, 64) != hipSuccess)
+			    hipMemset(T.stats, 0, 128) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
 		}
@@ -801,6 +801,14 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
 				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
 	}
+#ifdef TFREC_AMD_COOPSTAT
+	if (c->submit_seq == 3) {
+		(void)hipDeviceSynchronize();
+		unsigned long long st[16] = { 0 };
+		(void)hipMemcpy(st, c->win[set].stats, sizeof(st), hipMemcpyDeviceToHost);
+		fprintf(stderr, "COOPSTAT (3 submits) frozen one-block steps %llu, accepted %llu, rejected %llu, other frozen steps %llu\n", st[7], st[8], st[9], st[10]);
+	}
+#endif
 	if (getenv("TFREC_AMD_DEBUG_WINHIST") && c->submit_seq == 3) {  // (debug: the window length distribution of one submit)
 		(void)hipDeviceSynchronize();
 		const WinTables &T = c->win[set];

@@ -1509,6 +1509,9 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		v.l3 = lu[(g3_ <= last ? g3_ : last) - og];
 		return v;
 	};
+#ifdef TFREC_AMD_COOPSTAT
+	unsigned long long cs_steps = 0, cs_acc = 0, cs_rej = 0, cs_slow = 0;
+#endif
 	In4 nxt4 = load4(g1);
 	for (int gb4 = g1; gb4 <= last; gb4 += 256) {
 	const In4 cur4 = nxt4;
@@ -1519,18 +1522,20 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		const int gb = gb4 + 64 * q4;
 		if (gb > last)
 			break;
-		struct {
-			int ld;
-			uint32_t iq;
-		} cur;
-		cur.ld = (int)(int16_t)(q4 == 0 ? cur4.l0 : (q4 == 1 ? cur4.l1 : (q4 == 2 ? cur4.l2 : cur4.l3)));
-		cur.iq = bitcnt < 10 ? drow[gb + lane <= last ? gb + lane : last] : 0u;
+		const int ld = (int)(int16_t)(q4 == 0 ? cur4.l0 : (q4 == 1 ? cur4.l1 : (q4 == 2 ? cur4.l2 : cur4.l3)));
 		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
-		const bool valid = lane < nv;
-		const int ld = cur.ld;
 		if (bitcnt >= 10) {  // thresholds frozen: two ballots, then only the edges of the polarity that can flip last_bit
-			const unsigned long long m1 = __ballot(valid && ld > hi);
-			const unsigned long long m0 = __ballot(valid && ld < lo) & ~m1;
+			unsigned long long m1 = __ballot(ld > hi), m0 = __ballot(ld < lo);
+			if (nv < 64) {  // the window's last step (the lanes behind its end hold the last sample again)
+				const unsigned long long vm = (1ull << nv) - 1ull;
+				m1 &= vm;
+				m0 &= vm;
+			}
+			m0 &= ~m1;
+			// Two steps in three hold no sample that could flip last_bit (0.66 candidates per step on the benchmark's windows):
+			// nothing of the state moves then -- last_bit_idx is brought to a block where a candidate looks at it.
+			if ((last_bit ? m0 : m1) == 0ull)
+				continue;
 			const int o = gb & (kBlockDec - 1);
 			if (nb_mul && o + nv <= kBlockDec) {
 				// The step lies in ONE block (all but one in 128): last_bit_idx is brought to that block once, and the walk over
@@ -1544,10 +1549,16 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 				}
 				const int ibase = 2 * o;
 				unsigned long long todo = ~0ull;  // positions not yet visited
+#ifdef TFREC_AMD_COOPSTAT
+				cs_steps++;
+#endif
 				while (true) {
 					const unsigned long long m = (last_bit ? m0 : m1) & todo;
 					if (!m)
 						break;
+#ifdef TFREC_AMD_COOPSTAT
+					cs_rej++;
+#endif
 					const int k = __builtin_ctzll(m);
 					todo = ~1ull << k;
 					const int index = ibase + 2 * k, d = index - lbi;
@@ -1562,6 +1573,10 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 							const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
 							bw.put_bits((last_bit ? (1u << run) - 1u : 0u) | ((uint32_t)(last_bit ^ 1) << run), run + 1);
 							last_bit ^= 1;
+#ifdef TFREC_AMD_COOPSTAT
+							cs_acc++;
+							cs_rej--;
+#endif
 							continue;
 						}
 					}
@@ -1580,6 +1595,9 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 				continue;
 			}
 			unsigned long long todo = ~0ull;  // positions not yet visited
+#ifdef TFREC_AMD_COOPSTAT
+			cs_slow++;
+#endif
 			while (true) {
 				const unsigned long long m = (last_bit ? m0 : m1) & todo;
 				if (!m)
@@ -1611,8 +1629,10 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 			}
 			continue;
 		}
-		// I*I + Q*Q in the wrapping arithmetic of the reference binary (tfa2.cpp:373)
-		const int I = (int)(int16_t)(cur.iq & 0xffff), Q = (int)cur.iq >> 16;
+		// I*I + Q*Q in the wrapping arithmetic of the reference binary (tfa2.cpp:373; only this, the adaptive phase, looks at it)
+		const bool valid = lane < nv;
+		const uint32_t iq_ = drow[gb + lane <= last ? gb + lane : last];
+		const int I = (int)(int16_t)(iq_ & 0xffff), Q = (int)iq_ >> 16;
 		const uint32_t pw = (uint32_t)(I * I) + (uint32_t)(Q * Q);
 		int pos = 0;
 		while (pos < nv) {
@@ -1664,6 +1684,14 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	if (closed)  // tfa2.cpp:430-431: trailing bits before the flush
 		bw.put_run(last_bit, 16);
 	bw.finish();
+#ifdef TFREC_AMD_COOPSTAT
+	if (lane == 0) {
+		atomicAdd(&T.stats[7], cs_steps);
+		atomicAdd(&T.stats[8], cs_acc);
+		atomicAdd(&T.stats[9], cs_rej);
+		atomicAdd(&T.stats[10], cs_slow);
+	}
+#endif
 	if (lane == 0) {
 		WinResult r;
 		r.nbits = bw.n;
