@@ -438,6 +438,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 						break;
 					}
 				}
+				p.td_lo = (int)floor(p.spb / 4) + 1;
+				p.td_hi = (int)ceil(32 * p.spb) - 1;
 				p.iir = biquad_coef(0.5 / p.spb);  // tfa2.cpp:321
 			} else {
 				p.window = d2i_host(8 * p.spb);         // whb.cpp:641

@@ -1456,8 +1456,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	int cur_block = fresh ? og >> 13 : (g1 - 1) >> 13;
 	int lbi = r0.lbi_out;  // relative to cur_block (run_window leaves it relative to the block of its last sample)
 	// integer form of "tdiff > spb / 4 && tdiff < 32 * spb" (tdiff is an integer)
-	const int td_lo = __builtin_amdgcn_readfirstlane((int)floor(spb / 4) + 1);  // (scalars: the walk below is scalar code)
-	const int td_hi = __builtin_amdgcn_readfirstlane((int)ceil(32 * spb) - 1);
+	const int td_lo = L.params[a].td_lo, td_hi = L.params[a].td_hi;  // (from the kernel arguments: scalars, like the walk that uses them)
 	int hi = 0, lo = 0;
 	auto thresholds = [&]() {  // tfa2.cpp:379-381
 		const int noffset = d2i(0.9 * offset);
@@ -1512,11 +1511,86 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 #ifdef TFREC_AMD_COOPSTAT
 	unsigned long long cs_steps = 0, cs_acc = 0, cs_rej = 0, cs_slow = 0;
 #endif
+	// The walk over one step's candidates when the step lies in ONE block (all but one in 128): last_bit_idx is brought to
+	// that block, and the rest is plain scalar arithmetic on indices relative to the step -- an accepted edge appends its
+	// numbits - 1 copies of last_bit and the new bit in one go (tfa2.cpp:399-404).  Same rules as the general walk further
+	// down, which keeps the steps that straddle a block boundary (and contexts without the numbits multiplier).
+	auto walk_one_block = [&](const int gb, const unsigned long long m1, const unsigned long long m0) {
+		const int o = gb & (kBlockDec - 1);
+		const int b = gb >> 13;
+		if (b != cur_block) {
+			lbi = rebase_lbi(lbi, cur_block, b);
+			cur_block = b;
+		}
+		const int ibase = 2 * o;
+		unsigned long long todo = ~0ull;  // positions not yet visited
+#ifdef TFREC_AMD_COOPSTAT
+		cs_steps++;
+#endif
+		while (true) {
+			const unsigned long long m = (last_bit ? m0 : m1) & todo;
+			if (!m)
+				break;
+#ifdef TFREC_AMD_COOPSTAT
+			cs_rej++;
+#endif
+			const int k = __builtin_ctzll(m);
+			todo = ~1ull << k;
+			const int index = ibase + 2 * k, d = index - lbi;
+			if (first_cand_g < 0)
+				first_cand_g = gb + k;
+			if (d > 2)
+				lbi = index;  // tfa2.cpp:410-411 (d was taken first: the edge's timing uses the old value)
+			if (d > 8) {          // tfa2.cpp:391
+				bitcnt++;
+				if (d >= td_lo && d <= td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
+					const int numbits = tfa2_numbits_mul(d, nb_mul);
+					const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
+					bw.put_bits((last_bit ? (1u << run) - 1u : 0u) | ((uint32_t)(last_bit ^ 1) << run), run + 1);
+					last_bit ^= 1;
+#ifdef TFREC_AMD_COOPSTAT
+					cs_acc++;
+					cs_rej--;
+#endif
+					continue;
+				}
+			}
+			// not accepted: the run of candidates of the same polarity right behind it cannot be either (see below); it
+			// only moves last_bit_idx, to the last sample at which "index - lbi > 2" fired
+			const unsigned long long rest = m >> 1 >> k;
+			const int R = __builtin_ctzll(~rest);  // candidates at k + 1 .. k + R (rest has zeros at its top)
+			if (R > 0) {
+				const int e = index + 2 - lbi;  // index - lbi at sample k + 1 (<= 4)
+				const int t_set = e > 2 ? 1 : ((2 - e) >> 1) + 2;
+				if (t_set <= R)
+					lbi = index + 2 * (t_set + 2 * ((R - t_set) >> 1));
+				todo = ~1ull << (k + R);
+			}
+		}
+	};
 	In4 nxt4 = load4(g1);
 	for (int gb4 = g1; gb4 <= last; gb4 += 256) {
 	const In4 cur4 = nxt4;
 	if (gb4 + 256 <= last)
 		nxt4 = load4(gb4 + 256);
+	// A whole stretch of 256 samples with frozen thresholds inside the window and inside one block: the eight ballots first,
+	// then step by step -- a step without a sample that could flip last_bit (one in two) costs a scalar select and a
+	// compare; last_bit may have flipped in the step before, so the test is made in order.
+	if (bitcnt >= 10 && nb_mul && gb4 + 255 <= last && (gb4 & (kBlockDec - 1)) + 256 <= kBlockDec) {
+		const int l0 = (int)(int16_t)cur4.l0, l1 = (int)(int16_t)cur4.l1, l2 = (int)(int16_t)cur4.l2, l3 = (int)(int16_t)cur4.l3;
+		const unsigned long long h0 = __ballot(l0 > hi), h1 = __ballot(l1 > hi), h2 = __ballot(l2 > hi), h3 = __ballot(l3 > hi);
+		const unsigned long long w0 = __ballot(l0 < lo) & ~h0, w1 = __ballot(l1 < lo) & ~h1, w2 = __ballot(l2 < lo) & ~h2,
+					 w3 = __ballot(l3 < lo) & ~h3;
+		if ((last_bit ? w0 : h0) != 0ull)
+			walk_one_block(gb4, h0, w0);
+		if ((last_bit ? w1 : h1) != 0ull)
+			walk_one_block(gb4 + 64, h1, w1);
+		if ((last_bit ? w2 : h2) != 0ull)
+			walk_one_block(gb4 + 128, h2, w2);
+		if ((last_bit ? w3 : h3) != 0ull)
+			walk_one_block(gb4 + 192, h3, w3);
+		continue;
+	}
 #pragma unroll 1
 	for (int q4 = 0; q4 < 4; q4++) {
 		const int gb = gb4 + 64 * q4;
@@ -1538,60 +1612,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 				continue;
 			const int o = gb & (kBlockDec - 1);
 			if (nb_mul && o + nv <= kBlockDec) {
-				// The step lies in ONE block (all but one in 128): last_bit_idx is brought to that block once, and the walk over
-				// the candidates is plain scalar arithmetic on indices relative to the step -- an accepted edge appends its
-				// numbits - 1 copies of last_bit and the new bit in one go (tfa2.cpp:399-404).  Same rules as the general walk
-				// below, which keeps the steps that straddle a block boundary (and contexts without the numbits multiplier).
-				const int b = gb >> 13;
-				if (b != cur_block) {
-					lbi = rebase_lbi(lbi, cur_block, b);
-					cur_block = b;
-				}
-				const int ibase = 2 * o;
-				unsigned long long todo = ~0ull;  // positions not yet visited
-#ifdef TFREC_AMD_COOPSTAT
-				cs_steps++;
-#endif
-				while (true) {
-					const unsigned long long m = (last_bit ? m0 : m1) & todo;
-					if (!m)
-						break;
-#ifdef TFREC_AMD_COOPSTAT
-					cs_rej++;
-#endif
-					const int k = __builtin_ctzll(m);
-					todo = ~1ull << k;
-					const int index = ibase + 2 * k, d = index - lbi;
-					if (first_cand_g < 0)
-						first_cand_g = gb + k;
-					if (d > 2)
-						lbi = index;  // tfa2.cpp:410-411 (d was taken first: the edge's timing uses the old value)
-					if (d > 8) {          // tfa2.cpp:391
-						bitcnt++;
-						if (d >= td_lo && d <= td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
-							const int numbits = tfa2_numbits_mul(d, nb_mul);
-							const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
-							bw.put_bits((last_bit ? (1u << run) - 1u : 0u) | ((uint32_t)(last_bit ^ 1) << run), run + 1);
-							last_bit ^= 1;
-#ifdef TFREC_AMD_COOPSTAT
-							cs_acc++;
-							cs_rej--;
-#endif
-							continue;
-						}
-					}
-					// not accepted: the run of candidates of the same polarity right behind it cannot be either (see below); it
-					// only moves last_bit_idx, to the last sample at which "index - lbi > 2" fired
-					const unsigned long long rest = m >> 1 >> k;
-					const int R = __builtin_ctzll(~rest);  // candidates at k + 1 .. k + R (rest has zeros at its top)
-					if (R > 0) {
-						const int e = index + 2 - lbi;  // index - lbi at sample k + 1 (<= 4)
-						const int t_set = e > 2 ? 1 : ((2 - e) >> 1) + 2;
-						if (t_set <= R)
-							lbi = index + 2 * (t_set + 2 * ((R - t_set) >> 1));
-						todo = ~1ull << (k + R);
-					}
-				}
+				walk_one_block(gb, m1, m0);
 				continue;
 			}
 			unsigned long long todo = ~0ull;  // positions not yet visited

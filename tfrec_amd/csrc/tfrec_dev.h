@@ -74,6 +74,8 @@ struct ChainParams {
 	// slicer can pass (tdiff < 32 * spb) it equals (h * nb_mul + 2^39) >> 40 -- checked exhaustively against the fp64
 	// expression when the context is created; 0 = no multiplier passed the check, the kernels divide.
 	uint64_t nb_mul;
+	// tfa2.cpp:393 "tdiff > spb / 4 && tdiff < 32 * spb" for the integer tdiff: td_lo <= tdiff <= td_hi
+	int32_t td_lo, td_hi;
 };
 
 __host__ __device__ inline int tfa2_numbits_mul(int tdiff, uint64_t nb_mul)
