@@ -438,6 +438,9 @@ def main():
                     "roof_ms": vj["valu_roof_ms"], "busy_ms_counters": vj["valu_busy_ms_counters"],
                     "salu_roof_ms": vj["salu_roof_ms"], "salu_busy_ms_counters": vj["salu_busy_ms_counters"],
                     "frac": round(vj["valu_roof_ms"] / (elapsed / a.steps * 1e3), 4),
+                    # the roof the pipeline sits on: quad-cycles with an instruction of ANY kind in flight, over the 1024 SIMDs
+                    "issue_roof_ms": vj.get("issue_roof_ms"),
+                    "issue_frac": (round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4) if vj.get("issue_roof_ms") else None),
                     "sum_of_kernel_ms_alone": vj["sum_of_kernel_ms_alone"],
                     "how": "VALU wave-instructions of one batch by class (rocprofv3 --pmc, profiles/%s_pmc_mix.txt) x the measured "
                            "time per instruction and SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl: kernel time / "

@@ -9,6 +9,11 @@ Per batch (one batch = one frontend launch):
   valu_roof_ms = sum over classes of instructions x measured TIME per instruction and SIMD / 1024 SIMDs
   valu_busy_ms_counters = sum over kernels of SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz): the same roof from
                           the counters alone (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU within 4 %: four cycles per instruction)
+  issue_roof_ms = sum over kernels of SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x 2.4 GHz): the quad-cycles the batch's waves
+                  spend with an instruction of ANY kind in flight (vector, scalar, memory, LDS, branch), spread over the SIMDs.
+                  This is the roof the pipeline sits on: rounds 2 and 3 measured 7.97 / 8.1, 7.12 / 7.09 and 7.04 / 7.0 ms
+                  (roof / batch period) -- the batch's kernels are chains of dependent instructions with one to three waves per
+                  SIMD, which issue ONE instruction per SIMD and quad-cycle between them, whatever its kind
 The time per instruction is the microbenchmark's kernel time / (instructions per wave x waves per SIMD), the minimum over
 2, 4 and 8 waves per SIMD: 1.6-2.1 ns for the floating-point classes = 4 cycles of a 16-lane SIMD at 2.0-2.4 GHz, as the
 data sheet has it.  (Round 3's first version multiplied the benchmark's s_memtime ticks per instruction by 1 / 2.4 GHz.
@@ -47,7 +52,7 @@ cls_cost = {"fp64": cost["v_fma_f64"], "fma_f32": cost["v_pk_fma_f32"], "cvt": c
             "other": cost["v_fma_f32"], "salu": cost["s_add_u32"]}
 nb = max(d["dispatches"] for n, ds in valu.items() if n.startswith("frontend_kernel") for d in ds)
 kernels = {}
-busy_valu = busy_sca = 0.0
+busy_valu = busy_sca = busy_any = 0.0
 tot = dict(valu=0.0, fp64=0.0, fma_f32=0.0, cvt=0.0, int32=0.0, other=0.0, salu=0.0)
 for name, ds in valu.items():
     if name.startswith("__"):
@@ -66,9 +71,11 @@ for name, ds in valu.items():
         kernels[key] = dict(launches_per_batch=round(per, 2), insts_valu=nv, insts_salu=d.get("SQ_INSTS_SALU", 0), fp64=fp64,
                             fma_f32=f32, cvt=cvt, int32=i32, other=other, kernel_cycles_alone=gui_cycles,
                             kernel_ms_alone=round(gui_cycles / (CLOCK_GHZ * 1e6), 4),
-                            valu_busy=round(4.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, gui_cycles * N_SIMD), 4))
+                            valu_busy=round(4.0 * d.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, gui_cycles * N_SIMD), 4),
+                            inst_active_ms=round(4.0 * d.get("SQ_ACTIVE_INST_ANY", 0) * per / (N_SIMD * CLOCK_GHZ * 1e6), 4))
         busy_valu += 4.0 * d.get("SQ_ACTIVE_INST_VALU", 0) * per
         busy_sca += 4.0 * d.get("SQ_ACTIVE_INST_SCA", 0) * per
+        busy_any += 4.0 * d.get("SQ_ACTIVE_INST_ANY", 0) * per
         for c, v in (("valu", nv), ("fp64", fp64), ("fma_f32", f32), ("cvt", cvt), ("int32", i32), ("other", other),
                      ("salu", d.get("SQ_INSTS_SALU", 0))):
             tot[c] += v * per
@@ -78,8 +85,9 @@ out = dict(note=__doc__.strip(), ns_per_instruction_per_simd=cls_cost, per_batch
            valu_busy_ms_counters=round(busy_valu / (N_SIMD * CLOCK_GHZ * 1e6), 4),
            salu_roof_ms=round(tot["salu"] * cls_cost["salu"] / N_SIMD / 1e6, 4),
            salu_busy_ms_counters=round(busy_sca / (N_SIMD * CLOCK_GHZ * 1e6), 4),
+           issue_roof_ms=round(busy_any / (N_SIMD * CLOCK_GHZ * 1e6), 4),
            sum_of_kernel_ms_alone=round(sum(k["kernel_ms_alone"] * k["launches_per_batch"] for k in kernels.values()), 3),
            kernels=kernels)
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("per_batch", "ns_per_instruction_per_simd", "valu_roof_ms", "valu_busy_ms_counters",
-                                      "salu_roof_ms", "salu_busy_ms_counters", "sum_of_kernel_ms_alone")}, indent=1))
+                                      "salu_roof_ms", "salu_busy_ms_counters", "issue_roof_ms", "sum_of_kernel_ms_alone")}, indent=1))
