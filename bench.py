@@ -446,7 +446,9 @@ def main():
                            "time per instruction and SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl: kernel time / "
                            "(instructions per wave x waves per SIMD), 1.6-2.1 ns = 4 cycles) / 1024 SIMDs; busy_ms_counters = "
                            "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), the same roof from the counters alone; frac = "
-                           "roof_ms / ms_per_step; per kernel: profiles/%s_valu.json" % (ptag, ptag, ptag),
+                           "roof_ms / ms_per_step; issue_roof_ms = SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x 2.4 GHz): every kind of "
+                           "instruction together, the roof the batch sits on (DESIGN.md 7d), issue_frac = that / ms_per_step; per kernel: "
+                           "profiles/%s_valu.json" % (ptag, ptag, ptag),
                 }
             except Exception:
                 pass
