@@ -2827,7 +2827,7 @@ __device__ __forceinline__ double row_pick_f64(double v, int src)
 	return __hiloint2double(row_pick_i32(__double2hiint(v), src), row_pick_i32(__double2loint(v), src));
 }
 
-__global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
+__global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 							ChainLaunch L, int a, WinTables T, int *__restrict__ carry_io)
 {
 #ifdef TFREC_AMD_VERIFY_PRIO
@@ -2836,8 +2836,11 @@ __global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(cons
 	__builtin_amdgcn_s_setprio(TFREC_AMD_LAT_PRIO > 1 ? TFREC_AMD_LAT_PRIO : 1);
 #endif
 	const int M = n_blocks * kBlockDec;
-	const int ln = threadIdx.x, row = ln >> 4, li = ln & 15;
-	const int s = blockIdx.x * 4 + row;
+	// Workgroups of FOUR waves (independent: no barrier, no shared memory): a workgroup lands on one CU, a wave on each of
+	// its SIMDs.  As 256 one-wave workgroups the check sat on ONE SIMD of every CU of the chip, and the four-wave workgroups
+	// of the front end and the discriminator pass ran at the pace of their wave on that SIMD.
+	const int ln = threadIdx.x & 63, row = ln >> 4, li = ln & 15;
+	const int s = (blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 4 + row;
 	const bool active = s < n_streams;
 	const int sc_ = active ? s : 0;
 	const int c = a * n_streams + sc_;
@@ -3446,7 +3449,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		}
 		mark(26, P.vx);
 		if (!(skip & 16))
-		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 3) / 4), block, 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
+		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 15) / 16), dim3(256), 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
 				   T, P.whb_carry);
 		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly
 		hipLaunchKernelGGL((whb_demod_kernel<true, true>), dim3((n_streams + 63) / 64), block, 64 * 64, P.vx, dec, dec_stride, dev32, n_streams,
