@@ -638,6 +638,9 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 							 int n_blocks, ChainLaunch L, WinTables T, int16_t *__restrict__ ld16,
 							 int32_t *__restrict__ dev32, int lanes)
 {
+#ifdef TFREC_AMD_SPEC_PRIO
+	__builtin_amdgcn_s_setprio(TFREC_AMD_SPEC_PRIO);
+#endif
 	constexpr bool REPAIR = MODE != 0;
 	extern __shared__ __attribute__((aligned(16))) uint8_t k3_tile[];  // K3Tile<WHB>::kSize bytes
 	const int M = n_blocks * kBlockDec;

@@ -235,6 +235,9 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
+#ifdef TFREC_AMD_FMDEV_PRIO
+	__builtin_amdgcn_s_setprio(TFREC_AMD_FMDEV_PRIO);
+#endif
 	// A sample is read by a demodulator only inside a trigger window, i.e. if a trigger lies at most wmax - 1 samples
 	// before it (the first wmax samples of a submit may belong to a window left open by the previous one).  Decided
 	// per wave = per 256 samples: the mask words of [first - wmax, last], one per lane, one ballot.
