@@ -1298,14 +1298,15 @@ __global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void slicer_kernel(const ui
 // start == the true value bit for bit when it reaches the piece, and otherwise recomputes the piece itself:
 // exactness does not rest on the warm-up, only speed does.  16 lane-instructions per sample for 64 pieces at once
 // instead of 7 wave-instructions per sample.
-__global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void mark_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
+__global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void mark_kernel(const uint32_t *__restrict__ dec, size_t dec_stride, int n_streams,
 						  int n_blocks, ChainLaunch L, WinTables T)
 {
 	latency_prio();
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const uint32_t count = T.queue[7].count;
-	const uint32_t tid = blockIdx.x * 64 + threadIdx.x, nthreads = gridDim.x * 64;
+	// (four independent waves per workgroup, one on each SIMD of a CU: see whb_verify_kernel)
+	const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
 	for (uint32_t idx = tid; idx < count; idx += nthreads) {
 		const uint2 it = T.items[(size_t)7 * total + idx];
 		const int c = (int)it.x, j = (int)(it.y & 0x1ffffu), pc = (int)(it.y >> 17);
@@ -3467,7 +3468,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
 		if (kind == 0)
 			if (!(skip & 8))
-			hipLaunchKernelGGL(mark_kernel, dim3(std::max(1, win_blocks / 4)), block, 0, s_, dec, dec_stride, n_streams,
+			hipLaunchKernelGGL(mark_kernel, dim3(std::max(1, win_blocks / 16)), dim3(256), 0, s_, dec, dec_stride, n_streams,
 					   n_blocks, L, T);
 		// The lanes take their windows from a queue, so the wave count is a free parameter: fewer waves = fewer registers
 		// held for milliseconds by a latency-bound kernel (the front end beside it lives on what is left), more windows per lane
