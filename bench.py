@@ -135,8 +135,8 @@ def a_steps_in_profile(root, ptag):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=48, help="65536-byte blocks per stream per step")
     ap.add_argument("--types", type=lambda x: int(x, 16), default=0x2F)
