@@ -391,7 +391,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	static const int16_t wide[20] = { 546, 451, -317, -1844, -3198, -2817, 494, 6469, 13074, 17421,
 					  17421, 13074, 6469, 494, -2817, -3198, -1844, -317, 451, 546 };
 	for (int n = 0; n < 20; n++)
-		c->taps.f2[n] = (float)(cfg->filter_type ? wide[n] : narrow[n]) / 65536.0f;
+		c->taps.f2[n][0] = c->taps.f2[n][1] = (float)(cfg->filter_type ? wide[n] : narrow[n]) / 65536.0f;
 
 	// registration order, types and samples-per-bit of main.cpp:173-218
 	static const struct {
@@ -808,7 +808,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		(void)hipDeviceSynchronize();
 		unsigned long long st[16] = { 0 };
 		(void)hipMemcpy(st, c->win[set].stats, sizeof(st), hipMemcpyDeviceToHost);
-		fprintf(stderr, "COOPSTAT (3 submits) frozen one-block steps %llu, accepted %llu, rejected %llu, other frozen steps %llu\n", st[7], st[8], st[9], st[10]);
+		fprintf(stderr, "COOPSTAT (one submit) TFA_2 family: frozen one-block steps %llu, accepted %llu, rejected %llu, other frozen steps %llu; TFA_1: steps %llu, candidate runs %llu\n", st[7], st[8], st[9], st[10], st[11], st[12]);
 	}
 #endif
 	if (getenv("TFREC_AMD_DEBUG_WINHIST") && c->submit_seq == 3) {  // (debug: the window length distribution of one submit)

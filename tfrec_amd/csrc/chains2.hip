@@ -1771,8 +1771,17 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 	const MarkPiece *markrow = T.mark + (size_t)s * T.slots + slot0;
 	bool piece_ok = false;
 	MarkPiece mp = { 0, 0, 0, 0 };
+	// the candidate words of 64 steps at a time, a step per lane (fetched per step they were two scalar loads the wave
+	// waited for in every step)
+	uint32_t cw_lo = 0, cw_hi = 0;
 	for (int gb = og; gb <= last; gb += 64) {
 		const int step = (gb - og) >> 6;  // two slots per step, kMarkSlots / 2 steps per piece
+		if ((step & 63) == 0) {
+			const int sl = step + lane;
+			const bool in = og + 64 * sl <= last;
+			cw_lo = in ? candrow[2 * sl] : 0u;
+			cw_hi = in ? candrow[2 * sl + 1] : 0u;
+		}
 		if ((step & (kMarkSlots / 2 - 1)) == 0) {
 			mp = markrow[2 * step];
 			piece_ok = mp.start == mark;
@@ -1782,7 +1791,8 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
 		unsigned long long m;
 		if (piece_ok) {
-			const unsigned long long lo = candrow[2 * step], hi = nv > 32 ? candrow[2 * step + 1] : 0u;
+			const unsigned long long lo = (uint32_t)__builtin_amdgcn_readlane((int)cw_lo, step & 63);
+			const unsigned long long hi = nv > 32 ? (uint32_t)__builtin_amdgcn_readlane((int)cw_hi, step & 63) : 0u;
 			m = lo | (hi << 32);
 			if (gb + 64 > last || ((step + 1) & (kMarkSlots / 2 - 1)) == 0)
 				mark = mp.end;  // the piece ends with this step
@@ -1805,7 +1815,15 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 			m = __ballot(valid && dev < mk / 2);  // tfa1.cpp:164
 			atomicAdd(&T.stats[4], lane == 0 ? 1ull : 0ull);  // steps recomputed (tfrec_amd_get_stats)
 		}
+#ifdef TFREC_AMD_COOPSTAT
+		if (lane == 0)
+			atomicAdd(&T.stats[11], 1ull);
+#endif
 		while (m) {
+#ifdef TFREC_AMD_COOPSTAT
+			if (lane == 0)
+				atomicAdd(&T.stats[12], 1ull);
+#endif
 			const int k0 = __builtin_ctzll(m);
 			const unsigned long long inv = ~(m >> k0);
 			int len = inv ? __builtin_ctzll(inv) : 64 - k0;  // run of consecutive candidates
@@ -1824,8 +1842,13 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 			if (lbi) {
 				const int gap = i0 - lbi;
 				if (gap > 4) {
-					bw.put_run(1, gap >= 22 ? (gap - 22) / 20 + 1 : 0);  // ones for n = 22, 42, ... <= gap
-					bw.put_run(0, 1);
+					const int ones = gap >= 22 ? (gap - 22) / 20 + 1 : 0;  // ones for n = 22, 42, ... <= gap
+					if (ones < 32) {
+						bw.put_bits((1u << ones) - 1u, ones + 1);  // ... and the zero behind them, in one go
+					} else {
+						bw.put_run(1, ones);
+						bw.put_run(0, 1);
+					}
 				}
 			}
 			if (i0 - lbi > 2)

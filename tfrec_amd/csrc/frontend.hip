@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		f32x2 acc = { kMagic, kMagic };
 #pragma unroll
 		for (int n = 0; n < 20; n++)
-			acc = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n], taps.f2[n] }, acc);
+			acc = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc);
 		oI[o] = (int)(int16_t)(__float_as_uint(acc.x) & 0xffffu);
 		oQ[o] = (int)(int16_t)(__float_as_uint(acc.y) & 0xffffu);
 		outw[o] = ((uint32_t)oI[o] & 0xffffu) | ((uint32_t)oQ[o] << 16);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		f32x2 acc = { kMagic, kMagic };
 #pragma unroll
 		for (int n = 0; n < 20; n++)
-			acc = __builtin_elementwise_fma(y1[2 + n], f32x2{ taps.f2[n], taps.f2[n] }, acc);
+			acc = __builtin_elementwise_fma(y1[2 + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc);
 		prevdec[s] = (__float_as_uint(acc.x) & 0xffffu) | (__float_as_uint(acc.y) << 16);
 	}
 }

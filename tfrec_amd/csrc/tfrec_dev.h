@@ -27,7 +27,7 @@ constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per
 
 // Second-stage taps as h / 65536 (exact in fp32): the multiplier of the FMA form of the FIR stages (frontend.hip).
 struct FrontTaps {
-	float f2[20];
+	float f2[20][2];  // stage-2 taps / 65536, each twice: the (I, Q) operand of a packed FMA as it sits in a scalar register pair
 };
 
 // ---- biquad (dsp_stuff.cpp:28-56); state as the reference's members, coefficients in FrontParams
