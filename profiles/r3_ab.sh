@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="--steps 60 --warmup 5 --cpu-budget 0 --h2d-steps 0 --parity-streams 64 --no-extra-configs"
+B="--steps 100 --warmup 8 --cpu-budget 0 --h2d-steps 0 --parity-streams 64 --no-extra-configs"
 for lib in $LIBS; do
 if [ "$lib" != "default" ]; then export TFREC_AMD_LIB=$PWD/tfrec_amd/$lib; else unset TFREC_AMD_LIB; fi
 TFREC_AMD_SHORT_TAILS=0 python bench.py $B 2>/dev/null | python -c "
