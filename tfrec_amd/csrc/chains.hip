@@ -25,7 +25,7 @@
 
 namespace tfrec {
 
-__device__ __constant__ double kAtanPolySerial[11] = TFREC_ATAN_POLY;  // see dsp_dev.h
+__device__ __constant__ double kAtanPolySerial[16] = TFREC_ATAN_POLY;  // see dsp_dev.h
 
 template <int KIND>
 __device__ __forceinline__ void chain_body(const uint32_t *__restrict__ dec, size_t dec_stride,

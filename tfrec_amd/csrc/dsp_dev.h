@@ -79,12 +79,14 @@ __device__ __forceinline__ int fm_dev_nrzs(int ar, int aj, int br, int bj)
 #define TFREC_ATAN_POLY                                                                                                \
 	{ 0x1.fffffffffffffp-1, -0x1.5555555555101p-2, 0x1.9999999915220p-3, -0x1.249248f459b71p-3, 0x1.c71c601c68b53p-4, \
 	  -0x1.745b3a024febep-4, 0x1.3af4788c30195p-4, -0x1.0fc0caec4e264p-4, 0x1.cf80524e56f02p-5, -0x1.5cd7a4fac9dc7p-5, \
-	  0x1.47f65fb716232p-6 }
+	  0x1.47f65fb716232p-6,                                                                                           \
+	  /* [11..15]: tan(pi/8), pi/4, pi/2, pi, 16384 * (1/pi) -- in the same array so that they sit in scalar registers   \
+	     for the whole kernel instead of being re-materialised (two s_mov each) at every use */                        \
+	  0x1.a827999fcef32p-2, 0x1.921fb54442d18p-1, 0x1.921fb54442d18p+0, 0x1.921fb54442d18p+1, 16384.0 * (1.0 / 0x1.921fb54442d18p+1) }
 
 __device__ __forceinline__ double atan2_int(double cj, double cr, const double *__restrict__ poly)
 {
-	const double kPi = 0x1.921fb54442d18p+1, kPi2 = 0x1.921fb54442d18p+0, kPi4 = 0x1.921fb54442d18p-1;
-	const double kTanPi8 = 0x1.a827999fcef32p-2;
+	const double kTanPi8 = poly[11], kPi4 = poly[12], kPi2 = poly[13], kPi = poly[14];
 	const double ax = fabs(cr), ay = fabs(cj);
 	const double mx = fmax(ax, ay), mn = fmin(ax, ay);
 	const bool upper = mn > kTanPi8 * mx;  // the angle of (mx, mn) is above pi/8: atan(t) = pi/4 - atan((1-t)/(1+t))
@@ -143,7 +145,7 @@ __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out,
 	} else {
 		ang = atan2_int(cj, cr, atan_poly);
 	}
-	const double v = ang * kFmScale;
+	const double v = ang * atan_poly[15];  // kFmScale
 	*v_out = v;
 	return generic && fabs(v - rint(v)) < flag_eps;
 }

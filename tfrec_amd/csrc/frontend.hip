@@ -33,7 +33,7 @@
 
 namespace tfrec {
 
-__device__ __constant__ double kAtanPolyFront[11] = TFREC_ATAN_POLY;  // see dsp_dev.h
+__device__ __constant__ double kAtanPolyFront[16] = TFREC_ATAN_POLY;  // see dsp_dev.h
 
 // first-stage taps (dsp_stuff.cpp:119-130)
 __device__ __constant__ const int kS1[8] = { 2443, 6339, 11036, 14254, 14254, 11036, 6339, 2443 };
@@ -235,9 +235,13 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
 	const int m0 = tile * kTileDec;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-#ifdef TFREC_AMD_FMDEV_PRIO
-	__builtin_amdgcn_s_setprio(TFREC_AMD_FMDEV_PRIO);
+	// Wave priority 1: the pass heads the TFA_2 family's biquad stream, one of the two chains that end at the period.  At
+	// priority 0 the pipeline has two stable states -- this pass 1.8 ms inside the batch and the batch 6.6 ms, or 2.7 and
+	// 7.3 (two runs in five) --, at priority 1 or 2 only the first (nine runs of nine).
+#ifndef TFREC_AMD_FMDEV_PRIO
+#define TFREC_AMD_FMDEV_PRIO 1
 #endif
+	__builtin_amdgcn_s_setprio(TFREC_AMD_FMDEV_PRIO);
 	// A sample is read by a demodulator only inside a trigger window, i.e. if a trigger lies at most wmax - 1 samples
 	// before it (the first wmax samples of a submit may belong to a window left open by the previous one).  Decided
 	// per wave = per 256 samples: the mask words of [first - wmax, last], one per lane, one ballot.
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
 		double v;
 		unc[o] = fm_dev_fast(((double)I) * pI + ((double)Q) * pQ, ((double)Q) * pI - ((double)I) * pQ, &v, kAtanPolyFront, flag_eps);
-		dv[o] = d2i(v);
+		dv[o] = (int)v;  // |v| <= 16384: the range tests of d2i (x86's out-of-range result) can never fire
 		pI = I;
 		pQ = Q;
 	}
