@@ -23,12 +23,16 @@
 //                          demodulator needs the decoder's has_sync() (whb.cpp:653, 677, 693), which is tracked
 //                          with a lane-parallel evaluation of the (GF(2)-linear) sync search.  Output: bit runs.
 //                          In its tail (K4''): whb_decoder::store_bit over the runs, lane per window, then the
-//                          stream's flush events and decoder state.
+//                          stream's flush events and decoder state.  <false, false>: the decision levels from a
+//                          lane-parallel scan (speculated), every decision recorded;
+//   K4v whb_verify_kernel  the reference's own recurrence over those samples, four streams per wave, compares the
+//                          decisions and carries the exact filter state; failed streams are redone by
+//                          whb_demod_kernel<true, true> (the exact form), their events retracted.
 //   K5  decode_kernel      lane per window: the decoders (store_bit) over the window's packed bits;
 //       commit_kernel      lane per (stream, slot): walks the windows in order: checks the tfa2 speculation (a chain
 //                          with a window to re-run goes to commit_wave_kernel, wave per chain), overlays the windows'
 //                          rdata bytes, emits the flush events, commits ChainState for the next submit.
-// launch_pipeline (end of file) puts them on six streams: the stages of three consecutive submits run beside each
+// launch_pipeline (end of file) puts them on seven streams: the stages of four consecutive submits run beside each
 // other.
 #include <stdlib.h>
 
