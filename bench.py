@@ -135,7 +135,7 @@ def a_steps_in_profile(root, ptag):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
     ap.add_argument("--blocks", type=int, default=48, help="65536-byte blocks per stream per step")

@@ -117,6 +117,28 @@ def mint_kats(tmp):
     print("kat_bytes: %d cases pinned" % len(out))
 
 
+def mint_kat_debug(tmp):
+    """The decoders' diagnostics at debug levels -1 (-q), 1 (-D) and 2 (-D -D): the text the REAL reference prints for every
+    byte-level known answer (the '#NNN <time> ...' candidate lines, BAD lines, history entries), the wall-clock second
+    masked.  The host mirror (tfrec_amd/host/telegram.cpp) is compared with it in tests/test_host_cpp.py."""
+    import re
+    out = []
+    for types, hexline in KAT_BYTES:
+        hp = os.path.join(tmp, "katd.txt")
+        with open(hp, "w") as f:
+            f.write(hexline.strip() + "\n")
+        levels = {}
+        for lvl in (-1, 1, 2):
+            r = subprocess.run([O.REF_DRIVER, "hex", "%x" % types, hp, "", str(lvl)], capture_output=True, text=True, check=True)
+            text = r.stdout.split("---\n", 1)[1]
+            levels[str(lvl)] = re.sub(r"^(#\d{3}) \d+ ", r"\1 T ", text, flags=re.M)
+        out.append(dict(types=types, hex=" ".join(hexline.split()), text=levels))
+    with open(os.path.join(GOLD, "kat_debug.json"), "w") as f:
+        json.dump(dict(source="oracle/_ref/ref_driver hex <types> <file> '' <level> (real reference decoders); '#NNN <time>' masked to '#NNN T'",
+                       cases=out), f, indent=0)
+    print("kat_debug: %d cases x 3 debug levels pinned" % len(out))
+
+
 def compare_stream(iq, types, thresh, wide, tmp, tag, bits=True):
     """Run reference + oracle on one IQ array; returns the reference result after asserting equality."""
     p = os.path.join(tmp, "s.iq")
@@ -287,6 +309,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         if not a.no_mint:
             mint_kats(tmp)
+            mint_kat_debug(tmp)
             mint_unit_probes()
             mint_streams(tmp)
             mint_config5(tmp)

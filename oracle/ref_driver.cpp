@@ -20,7 +20,7 @@
 //   ref_driver runh <types_hex> <thresh> <wide 0|1> <iqfile> <mode 0|1>   (handler "echo REC": the reference's own
 //                   execute_handler() command lines, decoder.cpp:67-96, come out as "REC <args>" lines; mode = its -m;
 //                   flush_storage() of every decoder at the end like main.cpp:231-234)
-//   ref_driver hex  <types_hex> <hexfile>
+//   ref_driver hex  <types_hex> <hexfile> [<eventfile or ""> [<debug level: main.cpp -D / -q>]]
 //   ref_driver time <types_hex> <thresh> <wide 0|1> <iqfile> <repeat>
 //   ref_driver fmdev            (stdin int32[4] records -> stdout int32[2]: fm_dev, fm_dev_nrzs)
 //   ref_driver iir <cutoff>     (stdin doubles -> stdout doubles through a fresh iir2)
@@ -261,11 +261,11 @@ int main(int argc, char **argv)
 	if (!strcmp(argv[1], "hex") && argc >= 4) {
 		int types = strtol(argv[2], NULL, 16);
 		vector<demodulator *> demods;
-		register_demods(demods, types, 0);
+		register_demods(demods, types, argc > 5 ? atoi(argv[5]) : 0);  // [5]: the decoders' debug level (main.cpp -D)
 		puts("---");
 		FILE *fd = fopen(argv[3], "r");
 		if (!fd) { perror(argv[3]); return 2; }
-		if (argc > 4)
+		if (argc > 4 && strlen(argv[4]))
 			ev_fd = fopen(argv[4], "w");
 		char buf[1024];
 		while (fgets(buf, sizeof(buf), fd)) {

@@ -210,3 +210,19 @@ def test_bits_replay_reproduces_what_store_bit_prints(cli, golden_dir, tmp_path)
                                  capture_output=True, text=True, check=True).stdout
             got = [ln for ln in out.splitlines() if ln.strip() and not ln.startswith("WHB: Samples")]
             assert got == [ln for ln in want if ln != "Inverted SYNC"]
+
+
+def test_debug_diagnostics_equal_the_real_reference(cli, golden_dir, tmp_path):
+    """-q / -D / -D -D: the candidate lines ('#NNN <time> <bytes>'), BAD lines and history entries of tfa1.cpp:50-55,
+    tfa2.cpp:77-82,133-141,152-157,195-202 and whb.cpp:306-311,344-348,381-384,413-418,488-493,551-558, against what the
+    real reference printed for the same bytes (tests/golden/kat_debug.json, wall-clock second masked)."""
+    import re
+    cases = json.load(open(os.path.join(golden_dir, "kat_debug.json")))["cases"]
+    flags = {"-1": ["-q"], "1": ["-D"], "2": ["-D", "-D"]}
+    for c in cases:
+        f = tmp_path / "katd.txt"
+        f.write_text(c["hex"] + "\n")
+        for lvl, fl in flags.items():
+            out = subprocess.run([cli, "-T", "%x" % c["types"]] + fl + ["-X", str(f)], capture_output=True, text=True,
+                                 check=True).stdout
+            assert re.sub(r"^(#\d{3}) \d+ ", r"\1 T ", out, flags=re.M) == c["text"][lvl], (c["hex"], lvl)

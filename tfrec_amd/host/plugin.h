@@ -112,8 +112,10 @@ public:
 	void flush(int rssi, int offset = 0);
 
 private:
+	void debug_header(int nbytes, const char *tail);
 	uint32_t sr;
 	int sr_cnt;
+	int snum;  // telegrams printed in debug mode (tfa1.h:20)
 	crc8 crc;
 };
 
@@ -127,9 +129,11 @@ private:
 	void flush_tfa(int rssi, int offset);
 	void flush_tx22(int rssi, int offset);
 	void rearm();
+	void debug_header(int nbytes, const char *tail);
 	int invert;
 	uint32_t sr;
 	int sr_cnt;
+	int snum;
 	crc8 crc;
 };
 
@@ -144,6 +148,7 @@ private:
 	void payload(uint32_t stype, const uint8_t *msg, uint64_t id, int rssi);
 	uint32_t sr;
 	int sr_cnt;
+	int snum;
 	crc32 crc;
 	uint32_t raw_hist;  // last raw bits (whb.cpp:568-580 reduces to out[t] = b[t]^b[t-12]^b[t-17])
 };

@@ -151,7 +151,17 @@ static sensordata_t make_sd(sensor_e type, uint64_t id, double temp, double hum,
 static inline int bcd3(int hundreds, uint8_t lo) { return hundreds * 100 + (lo >> 4) * 10 + (lo & 0xf); }
 
 // ---------------------------------------------------------------- TFA_1 (KlimaLogg Pro): 2d d4 ID ID sT TT HH BB SS 56 CC
-tfa1_decoder::tfa1_decoder(sensor_e _type) : decoder(_type), sr(0), sr_cnt(-1), crc(0x31) { byte_cnt = 0; }
+tfa1_decoder::tfa1_decoder(sensor_e _type) : decoder(_type), sr(0), sr_cnt(-1), snum(0), crc(0x31) { byte_cnt = 0; }
+
+// debug mode (-D): every candidate telegram's running number, wall-clock second and first bytes ahead of the verdict
+// (tfa1.cpp:50-55)
+void tfa1_decoder::debug_header(int nbytes, const char *tail)
+{
+	printf("#%03i %u  ", snum++, (uint32_t)time(0));
+	for (int n = 0; n < nbytes; n++)
+		printf("%02x ", rdata[n]);
+	fputs(tail, stdout);
+}
 
 void tfa1_decoder::store_bit(int bit)  // LSB-first shift register, sync d4 2d in the oldest 16 bits
 {
@@ -177,12 +187,8 @@ void tfa1_decoder::flush(int rssi, int)
 		int hum = r[6];
 		const uint8_t want = crc.calc(&rdata[2], 8);
 		const bool learning_ok = (r[4] & 0xf0) == 0x80 || hum == 0x7f || hum == 0x6a;
-		if (dbg) {
-			printf("#--- %u  ", (uint32_t)time(0));
-			for (int n = 0; n < 11; n++)
-				printf("%02x ", r[n]);
-			printf("          ");
-		}
+		if (dbg)
+			debug_header(11, "          ");
 		if (r[10] == want && learning_ok && hum <= 0x7f && (r[7] & 0x60) == 0x60 && (r[8] & 0xf) == 0 && r[9] == 0x56) {
 			if (hum == 0x6a)  // temperature-only sensors
 				hum = 0;
@@ -213,7 +219,16 @@ void tfa1_decoder::flush(int rssi, int)
 }
 
 // ---------------------------------------------------------------- TFA_2 / TFA_3 / TX22
-tfa2_decoder::tfa2_decoder(sensor_e _type) : decoder(_type), invert(0), sr(0), sr_cnt(-1), crc(0x31) { byte_cnt = 0; }
+tfa2_decoder::tfa2_decoder(sensor_e _type) : decoder(_type), invert(0), sr(0), sr_cnt(-1), snum(0), crc(0x31) { byte_cnt = 0; }
+
+// (tfa2.cpp:77-82 with the telegram's byte count, :152-157 with seven bytes)
+void tfa2_decoder::debug_header(int nbytes, const char *tail)
+{
+	printf("#%03i %u  ", snum++, (uint32_t)time(0));
+	for (int n = 0; n < nbytes; n++)
+		printf("%02x ", rdata[n]);
+	fputs(tail, stdout);
+}
 
 void tfa2_decoder::store_bit(int bit)  // MSB-first shift register, sync 2d d4 (or its complement)
 {
@@ -256,6 +271,8 @@ void tfa2_decoder::flush_tfa(int rssi, int offset)
 {
 	const uint8_t *r = rdata;
 	if (byte_cnt >= 7) {
+		if (dbg)
+			debug_header(7, "                      ");
 		int id = (type << 28) | (r[2] << 8) | (r[3] & 0xc0);
 		const double temp = bcd3(r[3] & 0xf, r[4]) * 0.1 - 40;
 		int hum = r[5];
@@ -286,9 +303,17 @@ void tfa2_decoder::flush_tfa(int rssi, int offset)
 void tfa2_decoder::flush_tx22(int rssi, int offset)
 {
 	const uint8_t *r = rdata;
-	if (byte_cnt >= 7 && byte_cnt < 64 && (r[2] >> 4) == 0xa) {
+	const bool in_range = byte_cnt >= 7 && byte_cnt < 64;
+	uint8_t got = 0, want = 0;  // (both zero where the telegram fails before its CRC is looked at: "SANITY")
+	bool ok = false;
+	if (in_range && dbg)
+		debug_header(byte_cnt, "      ");
+	if (in_range && (r[2] >> 4) == 0xa) {
 		const int num = r[3] & 7;
-		if (r[2 * num + 4] == crc.calc(&rdata[2], 2 + 2 * num)) {
+		got = r[2 * num + 4];
+		want = crc.calc(&rdata[2], 2 + 2 * num);
+		if (got == want) {
+			ok = true;
 			const int sid = ((r[2] & 0xf) << 2) | (r[3] >> 6);
 			const int alarm = (!((r[3] >> 4) & 1)) | ((r[3] >> 3) & 1);  // error | low battery
 			bool have[5] = { false, false, false, false, false };
@@ -325,14 +350,23 @@ void tfa2_decoder::flush_tx22(int rssi, int offset)
 					sensordata_t sd = make_sd(type, (uint64_t)(int64_t)(base | out[k].sub), out[k].t, out[k].h, 0, alarm, rssi);
 					store_data(sd);
 				}
-		} else if (dbg)
-			printf("TX22(%02x) BAD RSSI %i len %i\n", 1 << type, rssi, byte_cnt);
+		}
+	}
+	if (!ok && dbg && in_range) {  // (counted in debug mode only: tfa2.cpp:133-134)
+		bad++;
+		if (got != want)
+			printf("TX22(%02x) BAD %i RSSI %i  Offset %.0lfkHz (CRC %02x %02x) len %i\n", 1 << type, bad, rssi,
+			       -1536.0 * offset / 131072, got, want, byte_cnt);
+		else
+			printf("TX22(%02x) BAD %i RSSI %i  Offset %.0lfkHz len %i (SANITY)\n", 1 << type, bad, rssi,
+			       -1536.0 * offset / 131072, byte_cnt);
+		fflush(stdout);
 	}
 	rearm();
 }
 
 // ---------------------------------------------------------------- WeatherHub: 4b 2d d4 2b LL ID*6 payload CRC32
-whb_decoder::whb_decoder(sensor_e _type) : decoder(_type), sr(0), sr_cnt(-1), crc(0x04c11db7), raw_hist(0) { byte_cnt = 0; }
+whb_decoder::whb_decoder(sensor_e _type) : decoder(_type), sr(0), sr_cnt(-1), snum(0), crc(0x04c11db7), raw_hist(0) { byte_cnt = 0; }
 
 void whb_decoder::store_bit(int bit)
 {
@@ -437,25 +471,42 @@ void whb_decoder::payload(uint32_t stype, const uint8_t *m, uint64_t id, int rss
 	case 0x08: {
 		const unsigned cnt = be16(m + 4), x1 = be16(m + 8);
 		if (show) printf("WHB08 ID %" PRIx64 " cnt %i\n", id, cnt);
+		for (int i = 0; i < 10 && dbg > 1; i++) {  // the ten event times (-D -D)
+			const unsigned x = be16(m + 6 + 2 * i);
+			printf("WHB08 ID %" PRIx64 " #%i time %i\n", id, i, k_unit_seconds[(x >> 14) & 3] * (x & 0x3fff));
+		}
 		emit(id, 2, cnt, k_unit_seconds[(x1 >> 14) & 3] * (x1 & 0x3fff), seq, rssi);
 		emit(id, 0, T11(2), 0, seq, rssi);
 		break;
 	}
 	case 0x0b: {  // wind: 24-bit sequence, values kept in single precision like the reference
 		const int seq24 = (m[0] << 16) | (m[1] << 8) | m[2];
-		const uint32_t v = ((uint32_t)m[3] << 24) | (m[4] << 16) | (m[5] << 8) | m[6];
-		const float dir = 22.5 * (v >> 28);
-		const float speed = (((v >> 16) & 0xff) + 256 * ((v >> 25) & 1)) * 0.1;
-		const float gust = (((v >> 8) & 0xff) + 256 * ((v >> 24) & 1)) * 0.1;
-		if (show) printf("WHB0b ID %" PRIx64 " #%i DIR %f SPEED %f GUST %f time %i\n", id, 0, dir, speed, gust, (v & 0xff) * 2);
+		float dir = 0, speed = 0, gust = 0;  // the newest of six history entries is the reading; -D prints them all
+		for (int i = 5; i >= 0; i--) {
+			const uint8_t *e = m + 3 + 4 * i;
+			const uint32_t v = ((uint32_t)e[0] << 24) | (e[1] << 16) | (e[2] << 8) | e[3];
+			dir = 22.5 * (v >> 28);
+			speed = (((v >> 16) & 0xff) + 256 * ((v >> 25) & 1)) / 10.0;
+			gust = (((v >> 8) & 0xff) + 256 * ((v >> 24) & 1)) / 10.0;
+			(void)0;
+		}
+		for (int i = 0; i < 6 && show && (i == 0 || dbg > 0); i++) {
+			const uint8_t *e = m + 3 + 4 * i;
+			const uint32_t v = ((uint32_t)e[0] << 24) | (e[1] << 16) | (e[2] << 8) | e[3];
+			const float d = 22.5 * (v >> 28), sp = (((v >> 16) & 0xff) + 256 * ((v >> 25) & 1)) / 10.0,
+				    gu = (((v >> 8) & 0xff) + 256 * ((v >> 24) & 1)) / 10.0;
+			printf("WHB0b ID %" PRIx64 " #%i DIR %f SPEED %f GUST %f time %i\n", id, i, d, sp, gu, (v & 0xff) * 2);
+		}
 		emit(id, 3, speed, dir, seq24, rssi);
 		emit(id, 4, gust, 0, seq24, rssi);
 		break;
 	}
 	case 0x10: {
 		const unsigned x0 = be16(m + 2), x1 = be16(m + 4);
-		if (show)
-			printf("WHB10 ID %" PRIx64 " #%i %i %i\n", id, 0, x0 >> 15, k_unit_seconds[(x0 >> 13) & 3] * (x0 & 0x1fff));
+		for (int i = 0; i < 4 && show && (i == 0 || dbg > 0); i++) {
+			const unsigned x = be16(m + 2 + 2 * i);
+			printf("WHB10 ID %" PRIx64 " #%i %i %i\n", id, i, x >> 15, k_unit_seconds[(x >> 13) & 3] * (x & 0x1fff));
+		}
 		emit(id, 5, x0 >> 15, k_unit_seconds[(x1 >> 13) & 3] * (x1 & 0x1fff), seq, rssi);
 		break;
 	}
@@ -463,6 +514,9 @@ void whb_decoder::payload(uint32_t stype, const uint8_t *m, uint64_t id, int rss
 		if (show) {
 			printf("WHB11 %" PRIx64 " TEMP1 %g HUM1 %i TEMP2 %g HUM2 %i TEMP3 %g HUM3 %i TEMP_IN %g HUM_IN %i", id, T11(2), H8(4),
 			       T11(6), H8(8), T11(10), H8(12), T11(14), H8(16));
+			if (dbg > 1)
+				printf(" PTEMP1 %g PHUM1 %i PTEMP2 %g PHUM2 %i PTEMP3 %g PHUM3 %i PTEMP_IN %g PHUM_IN %i", T11(18), H8(20), T11(22),
+				       H8(24), T11(26), H8(28), T11(30), H8(32));
 			puts("");
 		}
 		emit(id, 0, T11(14), H8(16), seq, rssi);
@@ -491,16 +545,23 @@ void whb_decoder::flush(int rssi, int)
 {
 	const uint8_t *r = rdata;
 	if (byte_cnt >= 11 && byte_cnt <= 60) {
+		if (dbg) {  // (whb.cpp:488-493; the verdict or the payload line follows on the same line)
+			printf("#%03i %u L=%i  ", snum++, (uint32_t)time(0), byte_cnt);
+			for (int n = 0; n < byte_cnt; n++)
+				printf("%02x ", r[n]);
+			printf(" RSSI %i ", rssi);
+		}
 		const int plen = r[4];
 		uint32_t init;
+		uint32_t want = 0, got = 0;
 		bool ok = false;
 		if (plen <= 60) {
 			if (!whb_crc_init(r[5], &init)) {
 				if (dbg >= 0)
 					printf("WHB: Probably unsupported sensor type %02x! Please report\n", r[5]);
 			} else {
-				const uint32_t want = crc.calc(&rdata[4], plen - 4, init);
-				const uint32_t got = ((uint32_t)r[plen] << 24) | (r[plen + 1] << 16) | (r[plen + 2] << 8) | r[plen + 3];
+				want = crc.calc(&rdata[4], plen - 4, init);
+				got = ((uint32_t)r[plen] << 24) | (r[plen + 1] << 16) | (r[plen + 2] << 8) | r[plen + 3];
 				if (want == got) {
 					uint64_t id = 0;
 					for (int n = 0; n < 6; n++)
@@ -510,8 +571,16 @@ void whb_decoder::flush(int rssi, int)
 				}
 			}
 		}
-		if (!ok)
+		if (!ok) {
 			bad++;
+			if (dbg) {
+				if (got != want)
+					printf("\nWHB BAD %i RSSI %i (CRC is %08x, should be %08x, len %i, plen %i)\n", bad, rssi, got, want, byte_cnt,
+					       plen);
+				else
+					printf("\nWHB BAD %i RSSI %i (SANITY)\n", bad, rssi);
+			}
+		}
 	}
 	sr_cnt = -1;
 	sr = 0;
