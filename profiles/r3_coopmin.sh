@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-B="--steps 60 --warmup 5 --cpu-budget 0 --h2d-steps 0 --parity-streams 64 --no-extra-configs"
-for t in 4096 3072 2048 1024 400; do TFREC_AMD_SHORT_TAILS=0 TFREC_AMD_COOP_MIN=$t python bench.py $B 2>/dev/null | python -c "
+B="--steps 100 --warmup 8 --cpu-budget 0 --h2d-steps 0 --parity-streams 64 --no-extra-configs"
+for t in 4096 3072 2048 1024 400; do TFREC_AMD_COOP_MIN=$t python bench.py $B 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=j['roofline']['kernels_ms']
