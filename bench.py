@@ -121,6 +121,49 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
     return res
 
 
+# ---- the algorithmic instruction floor of the path (SURVEY 8d "state both numbers"; derivation: DESIGN.md section 3)
+# Wave instructions the REFERENCE's arithmetic needs when every operation runs 64 lanes wide at one wave instruction per
+# SIMD and quad-cycle -- no control flow, no loads, no serial chain: what an ideal lane-parallel evaluation would issue.
+#   per complex INPUT sample:  9 packed FMAs (8 taps at 1/2 rate + 20 taps at 1/4 rate, I and Q per v_pk_fma_f32:
+#                              dsp_stuff.cpp:184-198, 213-226 -- the per-tap >>16 forbids folding symmetric taps) + 2 byte
+#                              conversions + 0.25 x (2 conversions back, |I|+|Q| > thresh: 3)                          = 12.25
+#   per decimated sample inside a TFA_2-family window (union of the three): fm_dev, dsp_stuff.cpp:284-292 = 6 fp64 for the
+#                              cross terms + atan2 (one division ~ 8, odd degree-21 polynomial 12, octant fix-up 6) + scale
+#                              and truncate 2                                                                         = 34
+#   per in-window sample of ONE TFA_2-family chain: iir2::step 9 fp64 (dsp_stuff.cpp:47-56) + 2 conversions + slicer
+#                              compares / threshold updates (tfa2.cpp:363-412) 8                                       = 19
+#   per in-window sample of TFA_1: fm_dev_nrzs 3 + peak detector 4 + pulse test 3 (tfa1.cpp:152-178)                   = 10
+#   per in-window sample of WHB: fm_dev_nrzs 3 + conversion 1 + iir 9 + (int) 1 + 0.5*dev and iir_avg 10 (while unsynced)
+#                              + (int), two compares, spacing test 4 (whb.cpp:651-664)                                 = 28
+# duty = the fraction of decimated samples inside a window of the chain, measured on the benchmark batch
+# (TFREC_AMD_DEBUG_WINHIST=1: profiles/r04_winhist.txt); bits, decoders and CRCs are per telegram: negligible.
+ALG_OPS = {"front": 12.25, "fm_dev": 34.0, "tfa2_chain": 19.0, "tfa1": 10.0, "whb": 28.0}
+ALG_DUTY = {"tfa1": 0.442, "tfa2": 0.437, "tfa3": 0.483, "tx22": 0.490, "whb": 0.467}  # profiles/r04_winhist.txt
+SIMDS, CLOCK_GHZ = 1024, 2.4
+
+
+def algorithmic_floor_ms(n_streams: int, n_blocks: int, types: int) -> dict:
+    n_in = float(n_streams) * n_blocks * SAMPLES_PER_BLOCK
+    n_dec = n_in / 4
+    lane_ops = ALG_OPS["front"] * n_in
+    fam = [k for k, bit in (("tfa2", 1), ("tfa3", 2), ("tx22", 3)) if types & (1 << bit)]
+    if fam:
+        lane_ops += ALG_OPS["fm_dev"] * n_dec * max(ALG_DUTY[k] for k in fam)
+        lane_ops += sum(ALG_OPS["tfa2_chain"] * n_dec * ALG_DUTY[k] for k in fam)
+    if types & 1:
+        lane_ops += ALG_OPS["tfa1"] * n_dec * ALG_DUTY["tfa1"]
+    if types & 0x20:
+        lane_ops += ALG_OPS["whb"] * n_dec * ALG_DUTY["whb"]
+    wave_insts = lane_ops / 64
+    return {"wave_instructions": round(wave_insts), "front_end_share": round(ALG_OPS["front"] * n_in / lane_ops, 3),
+            "ms": round(wave_insts * 4 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3, 4)}
+
+
+def alg_bytes_ms(n_streams, n_blocks, rate):
+    """the HBM floor: 2 B per complex input sample at the 8 TB/s peak"""
+    return round(2.0 * n_streams * n_blocks * SAMPLES_PER_BLOCK * rate / (HBM_PEAK_GBS * 1e9) * 1e3, 4)
+
+
 def a_steps_in_profile(root, ptag):
     """launches of the front end in the committed kernel trace = batches it covers"""
     try:
@@ -147,6 +190,9 @@ def main():
     ap.add_argument("--parity-streams", type=int, default=-1,
                     help="streams of the first batch checked against the CPU oracle: -1 = all at N=1, 128 spread over the "
                          "batch per rank at N>1; 0 = none")
+    ap.add_argument("--parity-after-streams", type=int, default=64,
+                    help="streams of the batch AFTER the timed region checked against the oracle continued over all "
+                         "repetitions of the input (a quarter of it per rank at N>1; needs --parity-streams != 0)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="backend of the barrier / scalar reduces at N>1 (the data path has no collective)")
     ap.add_argument("--same-device", action="store_true", help="tests: every rank uses cuda:0")
@@ -298,6 +344,43 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, red_dev)
+
+    # ---- parity of the state the timed region ran in (carried decoder / biquad / slicer / FIR state, FIFO `depth` deep): one
+    # more batch through the same context, a spread of its streams against the oracle CONTINUED over every repetition of
+    # the input this context has seen (gate + warm-up + timed steps + this one): decoder.cpp:118-122, tfa2.cpp:325-334,
+    # whb.cpp:616-623 carry state from block to block exactly like this
+    parity_after = None
+    parity_after_n = 0
+    if a.parity_streams != 0 and rate == 1:
+        from oracle import oracle as O
+        reps_before = (1 if parity_ok is not None else 0) + a.warmup + a.steps
+        r.submit(d_iq)
+        last = r.drain()
+        want_n = min(n_streams, a.parity_after_streams if world == 1 else max(8, a.parity_after_streams // 4))
+        pick = np.unique(np.linspace(0, n_streams - 1, want_n).round().astype(np.int64))
+        src = np.unique(pick % unique)
+        t_or = time.perf_counter()
+        orc = dict(zip(src.tolist(), O.process_parts([host[src], host[src]], a.types, a.thresh, 0, reps=[reps_before, 1],
+                                                     keep_from=1)))
+        t_or = time.perf_counter() - t_or
+        minb = np.array([10, 7, 7, 7, 11])
+        gs, gm = api.events_canon(last)
+        bounds = np.searchsorted(gs, np.arange(n_streams + 1))
+        parity_after = True
+        for sidx in pick.tolist():
+            e = orc[sidx % unique]
+            keep = (e["byte_cnt"] >= minb[e["slot"]]) & ~((e["slot"] == 3) & (e["byte_cnt"] >= 64)) & ~((e["slot"] == 4) & (e["byte_cnt"] > 60))
+            wm = O.canon(e[keep])
+            wm = wm[np.lexsort((wm[:, 1], wm[:, 0]))]
+            g = gm[bounds[sidx]:bounds[sidx + 1]]
+            g = g[np.lexsort((g[:, 1], g[:, 0]))]
+            if g.shape != wm.shape or not np.array_equal(g, wm):
+                parity_after = False
+                print("PARITY FAILURE after the timed region on rank %d stream %d" % (rank, sidx), file=sys.stderr)
+                break
+        parity_after_n = len(pick)
+        if shard.sum_over_ranks(0 if parity_after else 1, red_dev) != 0:
+            sys.exit(5)
     step_ms = np.diff(np.array(stamps)) * 1e3  # time between consecutive drains of this rank
     events_all = shard.sum_over_ranks(n_events, red_dev)
 
@@ -379,14 +462,19 @@ def main():
                     xr_.drain()
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - tx
+            xalg = algorithmic_floor_ms(xs, xb, xt) if not x10 else None
             extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, input_10x=x10, steps=steps, parity_ok=ok,
                                parity_streams_checked=xu,
                                ms_per_step=round(dt / steps * 1e3, 4),
+                               hbm_frac=round(2.0 * xs * xb * SAMPLES_PER_BLOCK * xr / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                               algorithmic_valu_floor_ms=(xalg["ms"] if xalg else None),
                                value=round(xs * xb * SAMPLES_PER_BLOCK * xr * steps / dt / 1e6, 1), unit="MSamples/s")
 
         try:
             side("configs[1]: one 1.536 MS/s stream, TFA_1/2/3 (-T 7)", 1, 48, 0x07, False, 30)
             side("configs[4]: 256 streams at 15.36 MS/s through the 10:1 front end, all five protocols", 256, 48, 0x2F, True, 8)
+            # the streaming kernels without the WHB chain's serial floor: configs[2]'s batch with the demodulators of configs[1]
+            side("1024 streams x TFA_1/2/3 (-T 7): no WHB chain", 1024, 48, 0x07, False, 12)
         except Exception as e:  # informative legs: never fail the line for them
             extra["error"] = str(e)[:200]
 
@@ -409,7 +497,9 @@ def main():
         traffic = traffic_total = prof_ms = traffic_source = None
         valu = None
         same_workload = (n_streams, n_blocks, a.types, rate) == (1024, 48, 0x2F, 1)
-        ptag = next((t for t in ("r03_final", "r03_mid") if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
+        ptag = next((t for t in ("r04_final", "r04_mid", "r03_final", "r03_mid")
+                     if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
+        chain_floor = fe_alone = None
         if ptag and same_workload:
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_traffic.json")))
@@ -439,19 +529,30 @@ def main():
                     "salu_roof_ms": vj["salu_roof_ms"], "salu_busy_ms_counters": vj["salu_busy_ms_counters"],
                     "frac": round(vj["valu_roof_ms"] / (elapsed / a.steps * 1e3), 4),
                     # the roof the pipeline sits on: quad-cycles with an instruction of ANY kind in flight, over the 1024 SIMDs
-                    "issue_roof_ms": vj.get("issue_roof_ms"),
-                    "issue_frac": (round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4) if vj.get("issue_roof_ms") else None),
+                    # (a UTILISATION figure, not a roofline: quad-cycles with an instruction of ANY kind in flight, of the
+                    # instructions this implementation issues, spread over the 1024 SIMDs)
+                    "issue_busy_ms": vj.get("issue_roof_ms"),
+                    "issue_busy_frac": (round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4) if vj.get("issue_roof_ms") else None),
                     "sum_of_kernel_ms_alone": vj["sum_of_kernel_ms_alone"],
+                    "source": "profiles/%s_valu.json (builder's rocprofv3 --pmc passes of this command; NOT measured in this run)" % ptag,
                     "how": "VALU wave-instructions of one batch by class (rocprofv3 --pmc, profiles/%s_pmc_mix.txt) x the measured "
                            "time per instruction and SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl: kernel time / "
                            "(instructions per wave x waves per SIMD), 1.6-2.1 ns = 4 cycles) / 1024 SIMDs; busy_ms_counters = "
                            "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), the same roof from the counters alone; frac = "
-                           "roof_ms / ms_per_step; issue_roof_ms = SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x 2.4 GHz): every kind of "
-                           "instruction together, the roof the batch sits on (DESIGN.md 7d), issue_frac = that / ms_per_step; per kernel: "
+                           "roof_ms / ms_per_step; issue_busy_ms = SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x 2.4 GHz): every kind of "
+                           "instruction this implementation issues, issue_busy_frac = that / ms_per_step; per kernel: "
                            "profiles/%s_valu.json" % (ptag, ptag, ptag),
                 }
+                # the serial floor: the dominant chain kernel ALONE on the chip (serial per stream; consecutive batches'
+                # launches of it run one after the other) and the only kernel that streams the input, alone
+                kj = vj.get("kernels", {})
+                chain_floor = kj.get(dom_name, {}).get("kernel_ms_alone")
+                fe_alone = next((v.get("kernel_ms_alone") for k, v in kj.items() if k.startswith("frontend_kernel")), None)
             except Exception:
                 pass
+        alg = algorithmic_floor_ms(n_streams, n_blocks, a.types) if rate == 1 else None
+        period_ms = elapsed / a.steps * 1e3
+        floors = [f for f in (chain_floor, alg["ms"] if alg else None, alg_bytes_ms(n_streams, n_blocks, rate)) if f]
         out = {
             "metric": "IQ MSamples/s through demod+decode (batched streams)",
             "value": round(value, 3),
@@ -479,6 +580,10 @@ def main():
                 "thresh": a.thresh, "parallelism": "streams sharded by index, no collective",
                 "events_per_step": n_events // max(1, a.steps), "parity_gate_streams": parity_n,
                 "parity_ok": parity_ok, "gen_seconds": round(t_gen, 2),
+                # the batch after the timed region (state carried over gate + warm-up + timed steps, FIFO `depth` deep)
+                # against the oracle continued over the same repetitions of the input
+                "parity_after_timed": parity_after, "parity_after_timed_streams": parity_after_n,
+                "parity_after_timed_batches_carried": (reps_before if parity_after is not None else None),
                 "atan_resolved": fm["resolved"], "atan_host_verified": fm["host_verified"],
                 "atan_host_mismatch": fm_bad, "atan_undecidable": fm["undecidable"],
                 # slow-path decisions beyond the per-submit log (62): exact by construction, but not compared with this host's libm
@@ -493,7 +598,18 @@ def main():
                 # other streams' kernels) | average of the same kernel in the committed kernel trace, per batch
                 "kernel_ms_hip_events": round(dom_ms, 4), "kernel_ms_profiles": prof_ms,
                 "profiles": ("profiles/%s_kernel_stats.txt" % ptag) if ptag and same_workload else None,
-                "valu": valu,
+                "valu_profiled": valu,
+                # ---- what binds (period / max(floors) = how far from the roof):
+                #  hbm_floor_ms             2 B per input sample at 8 TB/s
+                #  algorithmic_valu_floor_ms the reference's arithmetic, 64 lanes wide at one instruction per SIMD and quad-cycle
+                #  chain_floor_ms           the dominant serial kernel alone on the chip (profiles)
+                "hbm_floor_ms": alg_bytes_ms(n_streams, n_blocks, rate),
+                "algorithmic_valu_floor_ms": alg["ms"] if alg else None,
+                "algorithmic_valu_floor": alg,
+                "chain_floor_ms": chain_floor,
+                "period_over_max_floor": (round(period_ms / max(floors), 3) if floors else None),
+                "frontend": ({"ms_alone": fe_alone, "frac": round(alg_bytes / (fe_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "source": "profiles/%s_valu.json" % ptag} if fe_alone else None),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "whole_path_frac": round(alg_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5),
                 "traffic_total": traffic_total,

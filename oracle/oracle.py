@@ -82,6 +82,8 @@ def lib():
         L.orc_hex.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_process_many.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                        C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_process_parts.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_num_events.restype = C.c_size_t
         L.orc_num_events.argtypes = [C.c_void_p]
         L.orc_events.restype = C.POINTER(Event)
@@ -223,6 +225,30 @@ def process_many(iq: np.ndarray, types_mask: int = 0x2F, thresh: int = 500, wide
     lib().orc_process_many(types_mask, thresh, wide, a.ctypes.data, a.strides[0], a.shape[1], n,
                            threads or usable_threads(), out.ctypes.data, cap, counts.ctypes.data)
     assert counts.max(initial=0) <= cap, "orc_process_many: raise cap"
+    return [out[s, : counts[s]] for s in range(n)]
+
+
+def process_parts(parts, types_mask: int = 0x2F, thresh: int = 500, wide: int = 0, reps=None, keep_from: int = 0,
+                  cap: int = 4096, threads: int | None = None):
+    """Receivers that CONTINUE over several batches: parts = [iq_0[n_streams, n_bytes_0], iq_1, ...]; stream s runs
+    parts[p][s] reps[p] times in a row (default 1), parts in order, on one carried state -- the bytes of one long dump.
+    Returns one ORC_EVENT_DTYPE array per stream with the events from part `keep_from` on (end_sample counted from the
+    stream's first sample)."""
+    # (a part may be a column slice of a longer array: rows need not be adjacent, bytes of a row must be)
+    arrs = [p if (isinstance(p, np.ndarray) and p.dtype == np.uint8 and p.ndim == 2 and p.strides[1] == 1)
+            else np.ascontiguousarray(p, dtype=np.uint8) for p in parts]
+    n = arrs[0].shape[0]
+    assert all(a.ndim == 2 and a.shape[0] == n for a in arrs)
+    reps = list(reps) if reps is not None else [1] * len(arrs)
+    bases = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    strides = (C.c_size_t * len(arrs))(*[a.strides[0] for a in arrs])
+    nbytes = (C.c_size_t * len(arrs))(*[a.shape[1] for a in arrs])
+    creps = (C.c_int * len(arrs))(*reps)
+    out = np.zeros((n, cap), dtype=ORC_EVENT_DTYPE)
+    counts = np.zeros(n, dtype=np.int64)
+    lib().orc_process_parts(types_mask, thresh, wide, len(arrs), bases, strides, nbytes, creps, keep_from, n,
+                            threads or usable_threads(), out.ctypes.data, cap, counts.ctypes.data)
+    assert counts.max(initial=0) <= cap, "orc_process_parts: raise cap"
     return [out[s, : counts[s]] for s in range(n)]
 
 

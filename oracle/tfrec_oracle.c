@@ -1192,6 +1192,32 @@ void orc_process_many(int types_mask, int thresh, int wide, const uint8_t *iq, s
 	}
 }
 
+/* Batched checker over streams that CONTINUE across several input arrays ("parts": batches of a benchmark run): stream s
+ * runs part p (bases[p] + s * strides[p], nbytes[p] each) reps[p] times in a row on ONE receiver's carried state, parts in
+ * order -- what the reference does when the same bytes arrive as consecutive blocks of one long dump (engine.cpp:63-93).
+ * Only the events from part keep_from on are returned (the logs are cleared before it), end_sample counted from the
+ * stream's very first sample. */
+void orc_process_parts(int types_mask, int thresh, int wide, int n_parts, const uint8_t *const *bases, const size_t *strides,
+		       const size_t *nbytes, const int *reps, int keep_from, int n_streams, int threads, orc_event_t *out,
+		       size_t cap, int64_t *counts)
+{
+	build_tabs();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+	for (int s = 0; s < n_streams; s++) {
+		orc_t *o = orc_create(types_mask, thresh, wide);
+		for (int p = 0; p < n_parts; p++)
+			for (int r = 0; r < reps[p]; r++) {
+				if (p < keep_from || (p == keep_from && r == 0))
+					orc_clear_logs(o);
+				orc_process(o, bases[p] + (size_t)s * strides[p], nbytes[p]);
+			}
+		const size_t n = o->nev < cap ? o->nev : cap;
+		memcpy(out + (size_t)s * cap, o->ev, n * sizeof(orc_event_t));
+		counts[s] = (int64_t)o->nev;
+		orc_destroy(o);
+	}
+}
+
 /* main.cpp:45-49 with decoder::store_bytes (decoder.cpp:35-40) */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len)
 {

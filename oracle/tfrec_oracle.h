@@ -64,6 +64,12 @@ double orc_time_many(int types_mask, int thresh, int wide, const uint8_t *iq, si
 void orc_process_many(int types_mask, int thresh, int wide, const uint8_t *iq, size_t stride, size_t nbytes, int n_streams,
 		      int threads, orc_event_t *out, size_t cap, int64_t *counts);
 
+/* The same for streams that continue across several input arrays: part p (bases[p] + s * strides[p], nbytes[p]) is run
+ * reps[p] times in a row on the stream's one receiver; events from part keep_from on are returned */
+void orc_process_parts(int types_mask, int thresh, int wide, int n_parts, const uint8_t *const *bases, const size_t *strides,
+		       const size_t *nbytes, const int *reps, int keep_from, int n_streams, int threads, orc_event_t *out,
+		       size_t cap, int64_t *counts);
+
 /* -X replay (main.cpp:24-53): store_bytes + flush(0) on every registered decoder. */
 void orc_hex(orc_t *o, const uint8_t *bytes, int len);
 

@@ -428,16 +428,18 @@ def test_bits_mode_every_store_bit_equals_the_oracle(splits):
     assert n_bits > 20000
 
 
-def _all_streams_equal(ev, iq, types, thresh, all_flushes=True):
-    """every stream of the batch against the oracle (OpenMP, one receiver per stream): vectorised comparison"""
-    orc = O.process_many(iq, types, thresh, 0)
+def _all_streams_equal(ev, iq, types, thresh, all_flushes=True, wide=0, orc=None):
+    """every stream of the batch against the oracle (OpenMP, one receiver per stream): vectorised comparison.
+    orc: the oracle's events if they were computed already (one ORC_EVENT_DTYPE array per stream)"""
+    if orc is None:
+        orc = O.process_many(iq, types, thresh, wide)
     gs, gm = api.events_canon(ev)
     order = np.argsort(gs, kind="stable")  # (several drains concatenated: each is ordered by stream)
     gs, gm = gs[order], gm[order]
-    bounds = np.searchsorted(gs, np.arange(len(iq) + 1))
+    bounds = np.searchsorted(gs, np.arange(len(orc) + 1))
     minb = np.array([10, 7, 7, 7, 11])
     total = 0
-    for s in range(len(iq)):
+    for s in range(len(orc)):
         e = orc[s]
         if not all_flushes:
             e = e[(e["byte_cnt"] >= minb[e["slot"]]) & ~((e["slot"] == 3) & (e["byte_cnt"] >= 64)) & ~((e["slot"] == 4) & (e["byte_cnt"] > 60))]
@@ -595,3 +597,112 @@ def test_fm_dev_nrzs_probe_equals_the_real_reference(golden_dir):
     want = z["fm_out"][:, 1]
     assert np.array_equal(got, want)
     assert (np.abs(want) == 1000000000).sum() >= 100
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The state bench.py TIMES: 1024 streams x 48 blocks per submit, the FIFO kept four deep, decoder / biquad / slicer / FIR
+# state carried over five DIFFERENT batches (decoder.cpp:118-122 start() rebase, tfa2.cpp:325-334 "last_bit_idx and the
+# biquad state are not reset", whb.cpp:616-623) -- every stream's concatenated flush log against the oracle run over the
+# same 240 blocks as ONE long stream per receiver.
+_STEADY = {}
+
+
+def _steady_inputs():
+    """1024 streams of 240 blocks (5.1 s of signal each, bursts all the way through: windows span the batch boundaries),
+    cut into five 48-block batches; the oracle over each stream's 240 blocks in one go."""
+    if not _STEADY:
+        n_streams, n_blocks, n_batches = 1024, 48, 5
+        long_iq = synth.gen_batch(4000, 0, n_streams, n_blocks * n_batches)
+        row = n_blocks * 65536
+        _STEADY["batches"] = [long_iq[:, k * row:(k + 1) * row] for k in range(n_batches)]  # views
+        _STEADY["orc"] = O.process_many(long_iq, 0x2F, 500, 0, cap=2048)
+    return _STEADY["batches"], _STEADY["orc"]
+
+
+@pytest.mark.parametrize("force_fail", [0, 3], ids=["plain", "whb_every_third_stream_redone"])
+def test_config2_steady_state_five_batches_vs_oracle(force_fail, monkeypatch):
+    """BASELINE configs[2] in the state the benchmark times it: five different 1024 x 48-block batches through ONE
+    context with four submits in flight at all times (submit k+4 is queued before submit k is drained), all flushes, every
+    stream of every batch against the oracle run over the 240 blocks as one stream.  Second variant: every third
+    (stream + submit) fails its WHB check on purpose, so the exact redo of submit k (milliseconds, 341 streams) runs while
+    the speculative kernels of submits k+1 .. k+3 work on the same streams' live state (the redo must not work
+    in place)."""
+    import torch
+
+    if force_fail:
+        monkeypatch.setenv("TFREC_AMD_WHB_FORCE_FAIL", str(force_fail))
+    batches, orc = _steady_inputs()
+    n_streams, n_blocks = 1024, 48
+    dev = [torch.from_numpy(np.ascontiguousarray(b)).to("cuda:0") for b in batches]
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True, max_events=n_streams * n_blocks * 40) as r:
+        evs, q = [], 0
+        for k in range(len(dev)):
+            while q < len(dev) and q - k < api.FIFO_DEPTH:
+                r.submit(dev[q])
+                q += 1
+            evs.append(r.drain())
+        ev = np.concatenate(evs)
+        assert not (ev["status"] == 0xFF).any()
+        total = _all_streams_equal(ev, None, 0x2F, 500, orc=orc)
+        assert total > 5 * 80 * n_streams
+        assert r.fm_stats()["host_mismatch"] == 0
+        redone = r.stats()["whb_respeculated"]
+        if force_fail:
+            assert redone >= n_streams * len(dev) // force_fail
+        else:
+            assert redone <= 2, redone
+    # the batches really continue windows of the one before: flushes of windows that were open across a batch boundary
+    # (they fire less than the shortest window timeout after it) exist behind every boundary
+    M = n_blocks * 8192
+    for k in range(1, len(dev)):
+        early = sum(int(((e["end_sample"] >= k * M) & (e["end_sample"] < k * M + 300)).sum()) for e in orc)
+        assert early > 0, k
+
+
+def test_wide_filter_events_match_oracle():
+    """-W (dec_filter_taps1w, dsp_stuff.cpp:91-117, 176-178) down to the flush events, deterministic: 24 streams x 24
+    blocks, all five protocols, every flush, two submits."""
+    n_streams, n_blocks = 24, 24
+    iq = synth.gen_batch(314, 0, n_streams, n_blocks)
+    with api.Receiver(n_streams, 0x2F, 500, 1, max_blocks=16, all_flushes=True) as r:
+        r.submit(np.ascontiguousarray(iq[:, :16 * 65536]))
+        r.submit(np.ascontiguousarray(iq[:, 16 * 65536:]))
+        ev = np.concatenate([r.drain(), r.drain()])
+        total = _all_streams_equal(ev, iq, 0x2F, 500, wide=1)
+        assert total > 40 * n_streams
+        assert sorted(set(ev["slot"].tolist())) == [0, 1, 2, 3, 4]
+        assert r.fm_stats()["host_mismatch"] == 0
+    # (the wide filter is a different receiver: the narrow one's events differ on the same input)
+    narrow = O.process_many(iq[:4], 0x2F, 500, 0)
+    wide = O.process_many(iq[:4], 0x2F, 500, 1)
+    assert any(len(a) != len(b) or not np.array_equal(a, b) for a, b in zip(narrow, wide))
+
+
+@pytest.mark.parametrize("perturb", [3000, -20000, 150000])
+def test_whb_frozen_average_off_by_some_is_carried_into_a_redo(perturb, monkeypatch):
+    """A WHB window that is locked and still open at a submit boundary, whose speculated frozen decision level is NOT the
+    exact integer: the check accepts it if no candidate test could tell the two apart and carries the difference to the
+    next submit; if that submit then fails, the exact redo restores the snapshot (speculated integer) and must continue
+    the window with the exact one.  TFREC_AMD_WHB_TEST_PERTURB=D makes the speculative kernel freeze
+    (int)avg + D with the ambiguity rule widened to |D|; every second (stream + submit) is failed on purpose, so a passed
+    submit with a carry is always followed by a redo.  Submits of 1-3 blocks: most telegrams span a boundary."""
+    monkeypatch.setenv("TFREC_AMD_WHB_TEST_PERTURB", str(perturb))
+    monkeypatch.setenv("TFREC_AMD_WHB_FORCE_FAIL", "2")
+    n_streams, n_blocks = 48, 36
+    iq = synth.gen_batch(2718, 0, n_streams, n_blocks)
+    cuts = [0]
+    rng = np.random.default_rng(11)
+    while cuts[-1] < n_blocks:
+        cuts.append(min(n_blocks, cuts[-1] + int(rng.integers(1, 4))))
+    parts = [np.ascontiguousarray(iq[:, a * 65536:b * 65536]) for a, b in zip(cuts, cuts[1:])]
+    with api.Receiver(n_streams, 0x20, 500, 0, max_blocks=3, all_flushes=True) as r:
+        evs, q = [], 0
+        for k in range(len(parts)):
+            while q < len(parts) and q - k < api.FIFO_DEPTH:
+                r.submit(parts[q])
+                q += 1
+            evs.append(r.drain())
+        ev = np.concatenate(evs)
+        assert not (ev["status"] == 0xFF).any()
+        assert _all_streams_equal(ev, iq, 0x20, 500) > 2 * n_streams
+        assert r.stats()["whb_respeculated"] >= n_streams * len(parts) // 4

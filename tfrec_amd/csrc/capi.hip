@@ -98,6 +98,8 @@ struct tfrec_amd_ctx {
 	int *d_whbcarry = nullptr;                   // PipeCtl::whb_carry
 	uint32_t *d_whbgen = nullptr;                // WinTables::whbgen
 	ChainState *d_whbX = nullptr;                // WinTables::whbX
+	ChainState *d_whbscr = nullptr;              // WinTables::whbscr
+	int whb_test_perturb = 0;                    // TFREC_AMD_WHB_TEST_PERTURB (tests)
 	int whb_force_fail = 0;                      // TFREC_AMD_WHB_FORCE_FAIL (tests)
 	int submit_seq = 0;
 	hipStream_t vx = nullptr;                    // whb_verify_kernel: an alias of cp (deep layout) or of aux
@@ -304,6 +306,7 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_whbcarry);
 	(void)hipFree(c->d_whbgen);
 	(void)hipFree(c->d_whbX);
+	(void)hipFree(c->d_whbscr);
 	for (auto &e : c->ev_aux)
 		if (e)
 			(void)hipEventDestroy(e);
@@ -497,6 +500,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			ALLOC(c->d_whbcarry, n * sizeof(int));
 			ALLOC(c->d_whbgen, n * sizeof(uint32_t));
 			ALLOC(c->d_whbX, n * sizeof(ChainState));
+			ALLOC(c->d_whbscr, n * sizeof(ChainState));
+			if (const char *tp = getenv("TFREC_AMD_WHB_TEST_PERTURB"))
+				c->whb_test_perturb = atoi(tp);
 			if (rc == TFREC_AMD_OK && hipMemset(c->d_whbgen, 0, n * sizeof(uint32_t)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 			if (const char *ff = getenv("TFREC_AMD_WHB_FORCE_FAIL"))
@@ -569,6 +575,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.whbseen = (uint32_t *)(b + o_wseen);
 			T.whbgen = c->d_whbgen;
 			T.whbX = c->d_whbX;
+			T.whbscr = c->d_whbscr;
+			T.whbpub = nullptr;
+			T.whb_test_perturb = c->whb_test_perturb;
 			T.whb_force_fail = c->whb_force_fail;
 			T.whbx = c->d_whbx;
 			T.timeout_carry = c->d_tcarry;

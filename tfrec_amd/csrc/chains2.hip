@@ -2340,6 +2340,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				atomicAdd(&eb->dead, 1u);
 			}
 		}
+		// The redo launch's L.states[a] is the context's PRIVATE scratch array (T.whbscr): the speculative kernels of the
+		// submits behind this one read and write the live state (T.whbpub) in place while this runs for milliseconds.
 		const bool stale = T.whbseen[s] != T.whbgen[s];
 		const ChainState *from = stale ? &T.whbX[s] : &T.whbsnap[s];
 		if (ln < kStateChunks)
@@ -2353,6 +2355,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			st0.iir_avg.yn1 = x.y2;
 			st0.iir_avg.dn1 = 0.5 * (double)x.fd1;
 			st0.iir_avg.dn2 = 0.5 * (double)x.fd2;
+			// a locked window open at the submit's start: the snapshot froze the SPECULATED integer, the check accepted it as
+			// the exact one's neighbour (carry = exact - speculated, 0 unless such a window is open) -- the exact kernel must
+			// continue the window with the exact integer (whb.cpp:653-654)
+			st0.avg_of += x.carry;
 		}
 		__threadfence();
 		__syncthreads();
@@ -2401,6 +2407,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		WhbScan scan;
 		if (!EXACT)
 			whb_scan_init(scan, a1, a2, ln);
+		// A candidate test against the frozen average is AMBIGUOUS if it would come out differently with the average up to
+		// `tol` higher or lower: avg_of - dev in [-tol + 1, tol].  tol = 1 (the speculated (int) may be the exact one's
+		// neighbour); tests widen it and perturb the frozen integer (WinTables::whb_test_perturb).
+		const int perturb = EXACT ? 0 : T.whb_test_perturb;
+		const int amb_tol = perturb > 1 ? perturb : (perturb < -1 ? -perturb : 1);
+		const int amb_lo = amb_tol - 1;
+		const uint32_t amb_w = 2u * (uint32_t)amb_tol;
 		unsigned long long *const recrow = T.whbrec + (size_t)s * T.whbrec_stride;
 		int vstep = 0;
 
@@ -2554,7 +2567,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				} else {
 					mask = __ballot(ln < nv && dev < avg_of && rise);
 					if (!EXACT)
-						amb = amb || __ballot(ln < nv && rise && (uint32_t)(avg_of - dev) < 2u) != 0ull;
+						amb = amb || __ballot(ln < nv && rise && (uint32_t)(avg_of + amb_lo - dev) < amb_w) != 0ull;
 				}
 				// ---- (4) accepted candidates
 				int locked_at = -1;
@@ -2597,13 +2610,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 							y1 = yk;
 							fd2 = k > 0 ? dkm1 : fd1;
 							fd1 = dk;
-							avg_of = (int)yk;
+							avg_of = (int)yk + perturb;
 							lock_pos = kStep * i + k;
 							avg_frozen = avg_of;
 							// the rest of the step's candidates against the frozen avg_of
 							mask = __ballot(ln < nv && ln > k && dev < avg_of && rise);
 							if (!EXACT)
-								amb = amb || __ballot(ln < nv && ln > k && rise && (uint32_t)(avg_of - dev) < 2u) != 0ull;
+								amb = amb || __ballot(ln < nv && ln > k && rise && (uint32_t)(avg_of + amb_lo - dev) < amb_w) != 0ull;
 						}
 					}
 				}
@@ -2754,11 +2767,20 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	__syncthreads();
 	if (ln == 0)
 		whb_commit_stream(s, n_streams, n_blocks, sample_base, L, a, T, events, eb, flags, rdata_wave);
-	if (EXACT && redo) {  // the state later submits (speculated ones that started too early included) are redone from
+	if (EXACT && redo) {
+		// Publish the private copy: to whbX (what later redos of stale submits start from) and to the live state -- a
+		// speculative kernel that STARTS after the generation counter moved reads it and is not stale; one that started
+		// before (or is writing the live state right now) saw the old generation and will be redone from whbX whatever it
+		// reads or leaves behind.  State first, then the fence, then the counter.
 		__threadfence();
 		__syncthreads();
-		if (ln < kStateChunks)
-			reinterpret_cast<uint4 *>(&T.whbX[s])[ln] = reinterpret_cast<const uint4 *>(&L.states[a][s])[ln];
+		if (ln < kStateChunks) {
+			const uint4 v = reinterpret_cast<const uint4 *>(&L.states[a][s])[ln];
+			reinterpret_cast<uint4 *>(&T.whbX[s])[ln] = v;
+			reinterpret_cast<uint4 *>(&T.whbpub[s])[ln] = v;
+		}
+		__threadfence();
+		__syncthreads();
 		if (ln == 0) {
 			const ChainState &st1 = L.states[a][s];
 			WhbExact x;
@@ -2766,7 +2788,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			x.y2 = st1.iir_avg.yn1;
 			x.fd1 = (int)(2.0 * st1.iir_avg.dn1);
 			x.fd2 = (int)(2.0 * st1.iir_avg.dn2);
-			x.pad_[0] = x.pad_[1] = 0;
+			x.carry = x.pad_ = 0;
 			T.whbx[s] = x;
 			T.whbfail[s] = 0;
 			__threadfence();
@@ -2884,6 +2906,8 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 	double y1 = st.y1, y2 = st.y2;
 	int fd1 = st.fd1, fd2 = st.fd2;
 	int carry = carry_io[sc_];  // exact minus speculated frozen average of a window still open and locked (0, +1, -1)
+	const int carry_in = carry;
+	const int tol = T.whb_test_perturb > 1 ? T.whb_test_perturb : (T.whb_test_perturb < -1 ? -T.whb_test_perturb : 1);
 	bool bad = false, done = !active;
 	// the NEXT window's range is fetched while this one is filtered
 	WhbFilterRange nxt = whb_filter_range(T, c, 0, count, M, dvrow), cur = nxt;
@@ -2989,7 +3013,7 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 			i++;
 			if (i >= nsteps && cur.lock >= 0) {  // the decoder locked on this sample: the average it froze (whb.cpp:653-654)
 				const int delta = (int)y1 - cur.avgf;
-				bad = bad || delta > 1 || delta < -1 || (delta != 0 && (cur.wflags & 1));
+				bad = bad || delta > tol || delta < -tol || (delta != 0 && (cur.wflags & 1));
 				carry = (cur.wflags & 2) ? 0 : delta;
 			}
 #pragma unroll
@@ -2998,7 +3022,9 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 		}
 	}
 	if (active && li == 0) {
-		T.whbx0[s] = st;  // the exact state this submit started from (a redo needs it)
+		st.carry = carry_in;
+		st.pad_ = 0;
+		T.whbx0[s] = st;  // the exact state this submit started from, and the carry (a redo needs both)
 		// a stream whose speculative pass started from a state that a redo has replaced since is redone as well
 		bad = bad || T.whbseen[s] != T.whbgen[s];
 		if (T.whb_force_fail > 0 && (s + T.whb_submit_seq) % T.whb_force_fail == 0)
@@ -3007,7 +3033,7 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 		st.y2 = y2;
 		st.fd1 = fd1;
 		st.fd2 = fd2;
-		st.pad_[0] = st.pad_[1] = 0;
+		st.carry = st.pad_ = 0;
 		T.whbx[s] = st;
 		carry_io[s] = bad ? 0 : carry;  // (the exact kernel freezes the exact average: nothing to carry)
 		T.whbfail[s] = bad ? 1 : 0;
@@ -3482,9 +3508,14 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		if (!(skip & 16))
 		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 15) / 16), dim3(256), 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
 				   T, P.whb_carry);
-		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly
+		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly -- on the private
+		// state array: the speculative kernels of the submits behind this one work in place on the live one meanwhile
+		ChainLaunch Lr = L;
+		WinTables Tr = T;
+		Tr.whbpub = L.states[whb_verify];
+		Lr.states[whb_verify] = T.whbscr;
 		hipLaunchKernelGGL((whb_demod_kernel<true, true>), dim3((n_streams + 63) / 64), block, 64 * 64, P.vx, dec, dec_stride, dev32, n_streams,
-				   n_blocks, sample_base, L, whb_verify, T, events, eb, flags);
+				   n_blocks, sample_base, Lr, whb_verify, Tr, events, eb, flags);
 		mark(27, P.vx);
 		TRY(hipEventRecord(P.done[1], P.vx));
 	} else {

@@ -163,7 +163,8 @@ struct WhbStart {
 struct WhbExact {
 	double y1, y2;
 	int32_t fd1, fd2;
-	int32_t pad_[2];
+	int32_t carry;   // whbx0 only: exact minus speculated frozen average of a locked window open at the submit's start
+	int32_t pad_;
 };
 
 // TFA_1 peak detector (tfa1.cpp:157-160) over one piece of kMarkSlots slots of a long window, run by mark_kernel
@@ -238,6 +239,15 @@ struct WinTables {
 	ChainState *whbX;            // [n_streams] the chain state after the stream's last redone submit (ONE array per context)
 	int32_t whb_force_fail;      // tests (TFREC_AMD_WHB_FORCE_FAIL=N): declare every N-th (stream + submit) failed
 	int32_t whb_submit_seq;
+	// The redo works on a PRIVATE copy of the stream's chain state (whbscr, ONE array per context: redos run one after the
+	// other on vx) -- the speculative kernels of the submits behind it work in place on L.states meanwhile -- and publishes
+	// the result to whbX and to the live state (whbpub = L.states[whb slot], set for the redo launch only) at its end.
+	ChainState *whbscr;
+	ChainState *whbpub;
+	// tests (TFREC_AMD_WHB_TEST_PERTURB=D): the speculative kernel freezes (int)avg + D when the decoder locks, and "off by
+	// one" becomes "off by at most |D|" in the ambiguity rule and in the check: drives the carry / amb / redo paths of a
+	// window that spans submits with ordinary input.  0 in production (tolerance 1).
+	int32_t whb_test_perturb;
 };
 constexpr int kStatusDead = 0xff;  // tfrec_amd_event::status of a retracted event: never reported
 
@@ -277,7 +287,10 @@ constexpr int kNQueues = 8;
 // one more counter after the work queues, with a (stream, slot) list behind the queues' items: the TFA_2-family
 // chains whose commit found a window sliced under a wrong last_bit_idx assumption (commit_wave_kernel takes them)
 constexpr int kDeferQueue = kNQueues;
-constexpr int kSegSlots = 128;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
+#ifndef TFREC_AMD_SEG_SLOTS
+#define TFREC_AMD_SEG_SLOTS 128
+#endif
+constexpr int kSegSlots = TFREC_AMD_SEG_SLOTS;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
 constexpr int kSegConverged = 0x40000000, kSegRan = 0x20000000;
 constexpr int kLongWindow = 4096;  // samples; longer windows go to the wave-cooperative slicers (default).  The
                                    // lane-per-window slicers cost fewer instructions per sample (64 windows share a
