@@ -138,7 +138,7 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
 # duty = the fraction of decimated samples inside a window of the chain, measured on the benchmark batch
 # (TFREC_AMD_DEBUG_WINHIST=1: profiles/r04_winhist.txt); bits, decoders and CRCs are per telegram: negligible.
 ALG_OPS = {"front": 12.25, "fm_dev": 34.0, "tfa2_chain": 19.0, "tfa1": 10.0, "whb": 28.0}
-ALG_DUTY = {"tfa1": 0.442, "tfa2": 0.437, "tfa3": 0.483, "tx22": 0.490, "whb": 0.467}  # profiles/r04_winhist.txt
+ALG_DUTY = {"tfa1": 0.457, "tfa2": 0.455, "tfa3": 0.469, "tx22": 0.472, "whb": 0.463}  # profiles/r04_winhist.txt
 SIMDS, CLOCK_GHZ = 1024, 2.4
 
 
