@@ -37,6 +37,8 @@ using namespace tfrec;
 // Buffer / table sets = submits that may be in flight (the FIFO depth): front end of submit k+2, biquad stage of
 // k+1 and slicer stage of k run beside each other in the deep layout
 constexpr int kSets = TFREC_AMD_FIFO_DEPTH;
+// header of a set's event block: EventBuf + 16 bytes (the window tables' overflow flag), padded
+constexpr size_t kEvHeader = (sizeof(EventBuf) + 16 + 255) & ~(size_t)255;
 
 static thread_local char g_err[256] = "";
 
@@ -117,6 +119,7 @@ struct tfrec_amd_ctx {
 	// host still drains an older one
 	tfrec_amd_event *d_events[kSets] = {};
 	EventBuf *d_eb[kSets] = {};
+	uint8_t *d_evblock[kSets] = {}, *h_evblock[kSets] = {};  // what d_eb / d_events and h_eb / h_events point into
 	EventBuf *d_eb_fresh = nullptr;       // { 0, max_events, 0 }: copied over a set's EventBuf when a submit starts
 	// Pinned staging for the drain, one per set: the device-to-host copies of a submit's event buffer are queued on cp
 	// when the submit is made (behind its three end-of-chain events), so they are done when the host comes to drain it.
@@ -322,8 +325,7 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipFree(c->d_tail10[k]);
 	}
 	for (int k = 0; k < kSets; k++) {
-		(void)hipFree(c->d_events[k]);
-		(void)hipFree(c->d_eb[k]);
+		(void)hipFree(c->d_evblock[k]);
 		for (auto &e : c->done[k])
 			if (e)
 				(void)hipEventDestroy(e);
@@ -336,10 +338,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	}
 	(void)hipFree(c->d_eb_fresh);
 	for (int k = 0; k < kSets; k++) {
-		if (c->h_events[k])
-			(void)hipHostFree(c->h_events[k]);
-		if (c->h_eb[k])
-			(void)hipHostFree(c->h_eb[k]);
+		if (c->h_evblock[k])
+			(void)hipHostFree(c->h_evblock[k]);
 		if (c->copied[k])
 			(void)hipEventDestroy(c->copied[k]);
 	}
@@ -599,17 +599,28 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			ALLOC(c->d_tail10[k], n * 112);
 		}
 	}
+	// One block per set: [EventBuf | the window tables' overflow flag, 16 B | pad to 256 | events]: the drain's device-to-host
+	// copy of a submit is ONE copy on the stream that sets the batch period (three copies were 0.45 ms of it with their gaps)
 	for (int k = 0; k < kSets; k++) {
-		ALLOC(c->d_events[k], (size_t)cfg->max_events * sizeof(tfrec_amd_event));
-		ALLOC(c->d_eb[k], sizeof(EventBuf));
+		ALLOC(c->d_evblock[k], kEvHeader + (size_t)cfg->max_events * sizeof(tfrec_amd_event));
+		if (rc == TFREC_AMD_OK) {
+			c->d_eb[k] = (EventBuf *)c->d_evblock[k];
+			c->d_events[k] = (tfrec_amd_event *)(c->d_evblock[k] + kEvHeader);
+			if (c->win[k].count)  // (window-parallel pipeline: its overflow flag lives behind the EventBuf)
+				c->win[k].overflow = (int32_t *)(c->d_evblock[k] + sizeof(EventBuf));
+		}
 	}
-	ALLOC(c->d_eb_fresh, sizeof(EventBuf));
+	ALLOC(c->d_eb_fresh, sizeof(EventBuf) + 16);
 #undef ALLOC
-	for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++)
-		if (hipHostMalloc((void **)&c->h_events[k], (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
-		    hipHostMalloc((void **)&c->h_eb[k], sizeof(EventBuf) + 16, hipHostMallocDefault) != hipSuccess ||  // + the window tables' overflow flag
-		    hipEventCreateWithFlags(&c->copied[k], hipEventDisableTiming) != hipSuccess)
+	for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++) {
+		if (hipHostMalloc((void **)&c->h_evblock[k], kEvHeader + (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
+		    hipEventCreateWithFlags(&c->copied[k], hipEventDisableTiming) != hipSuccess) {
 			rc = TFREC_AMD_E_NOMEM;
+			break;
+		}
+		c->h_eb[k] = (EventBuf *)c->h_evblock[k];
+		c->h_events[k] = (tfrec_amd_event *)(c->h_evblock[k] + kEvHeader);
+	}
 	// Every pipeline stream except the biquad stages runs at high priority.  With the front end at low priority
 	// ("fill what the latency-bound chains leave free") its kernel stretched from 3 to 11 ms beside the chains and,
 	// with three submits in flight, became the longest stage of all: 13.4 ms per batch instead of 11.7.
@@ -634,6 +645,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    hipMemset(c->d_tail[1], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
 		    (c->in10x && (hipMemset(c->d_tail10[0], 0x80, n * 112) != hipSuccess ||
 				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
+		    hipMemset(c->d_eb_fresh, 0, sizeof(EventBuf) + 16) != hipSuccess ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    mkstream(&c->fs, 0, prio_fs) != hipSuccess ||
 		    mkstream(&c->cp, 1, 0) != hipSuccess ||
@@ -649,6 +661,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 					rc = TFREC_AMD_E_HIP;
 			if (hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming) != hipSuccess ||
 			    hipEventCreateWithFlags(&c->ev_front[k], hipEventDisableTiming) != hipSuccess ||
+			    hipMemset(c->d_evblock[k], 0, kEvHeader) != hipSuccess ||
 			    hipMemcpy(c->d_eb[k], &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
@@ -739,7 +752,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		HIPCHK(hipEventRecord(c->ev_in[set], (hipStream_t)hip_stream));
 		HIPCHK(hipStreamWaitEvent(fs, c->ev_in[set], 0));
 	}
-	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf), hipMemcpyDeviceToDevice, fs));
+	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf) + 16, hipMemcpyDeviceToDevice, fs));  // (+ the overflow flag)
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][0], fs));
 	const uint8_t *fin = (const uint8_t *)d_iq;
@@ -856,13 +869,9 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	hipStream_t cpy = c->cp;
 	for (auto &e : c->done[set])
 		HIPCHK(hipStreamWaitEvent(cpy, e, 0));
-	HIPCHK(hipMemcpyAsync(c->h_eb[set], c->d_eb[set], sizeof(EventBuf), hipMemcpyDeviceToHost, cpy));
 	c->copied_n[set] = std::min<uint32_t>(c->copy_guess, (uint32_t)c->cfg.max_events);
-	HIPCHK(hipMemcpyAsync(c->h_events[set], c->d_events[set], (size_t)c->copied_n[set] * sizeof(tfrec_amd_event),
-			      hipMemcpyDeviceToHost, cpy));
-	memset(c->h_eb[set] + 1, 0, 4);
-	if (c->win[set].overflow)
-		HIPCHK(hipMemcpyAsync(c->h_eb[set] + 1, c->win[set].overflow, 4, hipMemcpyDeviceToHost, cpy));
+	HIPCHK(hipMemcpyAsync(c->h_evblock[set], c->d_evblock[set], kEvHeader + (size_t)c->copied_n[set] * sizeof(tfrec_amd_event),
+			      hipMemcpyDeviceToHost, cpy));  // header, overflow flag and the first copied_n events in one go
 	HIPCHK(hipEventRecord(c->copied[set], cpy));
 	if (timing)
 		c->timed = true;

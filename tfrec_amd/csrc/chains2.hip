@@ -2774,10 +2774,16 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		// reads or leaves behind.  State first, then the fence, then the counter.
 		__threadfence();
 		__syncthreads();
+		// ... except ChainState::iir: the stage-1 low-pass state belongs to the biquad stage (fix_chain), which has carried it
+		// on through the submits behind this one while the redo ran -- a whole-state copy (as the in-place restore of round 3
+		// was) puts a value of several submits ago back and every later stage-1 output of the stream is wrong
+		constexpr int kIirChunk0 = (int)(offsetof(ChainState, iir) / 16), kIirChunk1 = (int)(offsetof(ChainState, iir_avg) / 16);
+		static_assert(offsetof(ChainState, iir) % 16 == 0 && offsetof(ChainState, iir_avg) % 16 == 0, "ChainState::iir must fill whole 16-byte chunks");
 		if (ln < kStateChunks) {
 			const uint4 v = reinterpret_cast<const uint4 *>(&L.states[a][s])[ln];
 			reinterpret_cast<uint4 *>(&T.whbX[s])[ln] = v;
-			reinterpret_cast<uint4 *>(&T.whbpub[s])[ln] = v;
+			if (ln < kIirChunk0 || ln >= kIirChunk1)
+				reinterpret_cast<uint4 *>(&T.whbpub[s])[ln] = v;
 		}
 		__threadfence();
 		__syncthreads();
