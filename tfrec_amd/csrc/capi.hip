@@ -517,7 +517,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
 		ALLOC(c->d_ld16[set], chains * (size_t)T.slots * 32 * sizeof(int16_t));
 		if (whb)
-			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t) + 1024);  // + slack: whb_demod_kernel keeps two 64-sample steps in flight past a row's last window
+			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t) + 4096);  // + slack: whb_demod_kernel keeps two 64-sample steps in flight past a row's last window
 		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
 		const size_t wins = chains * (size_t)T.cap;
 		size_t off = 0;
@@ -538,8 +538,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
 		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4);
 		const size_t o_cand = carve(n * (size_t)T.slots * 4), o_mark = carve(n * (size_t)T.slots * sizeof(MarkPiece));
-		T.whbrec_stride = (int32_t)(m_max / 64 + (size_t)T.cap + 2);
-		const size_t o_wrec = carve(whb ? n * (size_t)T.whbrec_stride * 8 : 0), o_wfail = carve(whb ? n * 4 : 0);
+		T.whbrec_stride = (int32_t)(m_max / 64 + 2 * (size_t)T.cap + 2 + kWhbRecSlack);
+		const size_t o_wrec = carve(whb ? n * (size_t)T.whbrec_stride * sizeof(WhbStepRec) : 0), o_wfail = carve(whb ? n * 4 : 0);
 		const size_t o_wsnap = carve(whb ? n * sizeof(ChainState) : 0), o_wx0 = carve(whb ? n * sizeof(WhbExact) : 0);
 		const size_t o_wseen = carve(whb ? n * 4 : 0);
 		ALLOC(c->win_block[set], off);
@@ -568,7 +568,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.segfix2 = (int32_t *)(b + o_sfix2);
 			T.cand = (uint32_t *)(b + o_cand);
 			T.mark = (MarkPiece *)(b + o_mark);
-			T.whbrec = (unsigned long long *)(b + o_wrec);
+			T.whbrec = (WhbStepRec *)(b + o_wrec);
 			T.whbfail = (int32_t *)(b + o_wfail);
 			T.whbsnap = (ChainState *)(b + o_wsnap);
 			T.whbx0 = (WhbExact *)(b + o_wx0);

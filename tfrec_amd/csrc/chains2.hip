@@ -2166,6 +2166,10 @@ __device__ __forceinline__ void whb_commit_stream(int s, int n_streams, int n_bl
 // When the decoder locks at sample k of a step, y(0..k) is already in LDS: the filter state is taken at k and the
 // candidates after k are re-tested against the frozen average -- no rewind.
 // The decoder stages (whb_decode_window, whb_commit_stream) run in the tail, by the same wave.
+#ifndef TFREC_AMD_WHB_AHEAD
+#define TFREC_AMD_WHB_AHEAD 1
+#endif
+constexpr int kWhbAhead = TFREC_AMD_WHB_AHEAD;  // whb_demod_kernel: steps whose stage-1 outputs are held ahead of the current one (one more is being loaded)
 constexpr uint32_t kWhbSyncRev = 0xd2b42bd4u;  // bit-reversed 0x2bd42d4b (whb.cpp:582): newest bit at the LSB
 
 __device__ __forceinline__ int wave_shr1(int v)  // lane n <- lane n-1 (lane 0: 0)
@@ -2414,7 +2418,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		const int amb_tol = perturb > 1 ? perturb : (perturb < -1 ? -perturb : 1);
 		const int amb_lo = amb_tol - 1;
 		const uint32_t amb_w = 2u * (uint32_t)amb_tol;
-		unsigned long long *const recrow = T.whbrec + (size_t)s * T.whbrec_stride;
+		WhbStepRec *const recrow = T.whbrec + (size_t)s * T.whbrec_stride;
 		int vstep = 0;
 
 		// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
@@ -2445,10 +2449,14 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			const bool closed = close < M;
 			const int n = (closed ? close : M - 1) - og + 1;
 			const int nch = (n + kStep - 1) / kStep;
-			const int32_t *wp = dvrow + (size_t)win_slot0(og, j) * 32 + ln;  // the lane's stage-1 output of step 0
+			const int slot0 = win_slot0(og, j);
+			const int32_t *wp = dvrow + (size_t)slot0 * 32 + ln;  // the lane's stage-1 output of step 0
 			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
-			// two steps stay in flight (past the window's end: the row's next slots or the slack behind it, never used)
-			int cur = wp[0], nx1 = wp[kStep];
+			// kWhbAhead steps stay in flight (past the window's end: the row's next slots or the slack behind it, never used)
+			int cur = wp[0], nxt[kWhbAhead];
+#pragma unroll
+			for (int k = 0; k < kWhbAhead; k++)
+				nxt[k] = wp[kStep * (k + 1)];
 			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
 				racc = 0;
@@ -2492,7 +2500,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			for (int i = 0; i < nch; i++) {
 				// ---- (1) this step's inputs; the next two steps' are in flight
 				const int nv = n - kStep * i < kStep ? n - kStep * i : kStep;
-				const int nx2 = wp[kStep * (i + 2)];
+				const int nxn = wp[kStep * (i + kWhbAhead + 1)];
 				const int dev = cur;
 				const int sh1 = wave_shr1(dev);
 				const int devm1 = ln == 0 ? last_dev : sh1;  // dev > last_dev (whb.cpp:663): the sample before the step
@@ -2559,8 +2567,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
 					const unsigned long long below = __ballot(ln < nv && dev < (int)ym);
 					if (!EXACT) {
-						if (ln == 0)
-							recrow[vstep] = below;
+						if (ln == 0) {  // (where the decoder locks in this step, the window's end rewrites meta and avgf)
+							WhbStepRec r;
+							r.below = below;
+							r.meta = (uint32_t)(slot0 + 2 * i) | ((uint32_t)(nv - 1) << kWhbRecNvShift);
+							r.avgf = 0;
+							recrow[vstep] = r;
+						}
 						vstep++;
 					}
 					mask = below & __ballot(rise);
@@ -2648,8 +2661,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					iq0 = iq1;
 					iq1 = iq_load(i + 2);
 				}
-				cur = nx1;
-				nx1 = nx2;
+				cur = nxt[0];
+#pragma unroll
+				for (int k = 0; k + 1 < kWhbAhead; k++)
+					nxt[k] = nxt[k + 1];
+				nxt[kWhbAhead - 1] = nxn;
 #ifdef TFREC_AMD_PROFILE_WHB
 				pf_tail += __builtin_readcyclecounter() - pf_mark;
 #endif
@@ -2704,6 +2720,35 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			res.resume = -1;
 			if (ln == 0)
 				T.result[(size_t)c * T.cap + j] = res;
+			if (!EXACT) {
+				// whb_verify_kernel's view of the window's end: the filter's run ended with a lock (the step's record says on
+				// which sample, what was frozen, and whether the rest of the window could tell it from its neighbours), or the
+				// window never ran the filter (it began locked: one record without a step)
+				const uint32_t wfl = (amb ? kWhbRecAmb : 0u) | (res.closed ? kWhbRecClosed : 0u);
+				if (lock_pos >= 0) {
+					if (ln == 0) {
+						WhbStepRec *r = &recrow[vbase + (lock_pos >> 6)];
+						r->meta = (uint32_t)(slot0 + 2 * (lock_pos >> 6)) | ((uint32_t)(lock_pos & 63) << kWhbRecNvShift) | kWhbRecLock | wfl;
+						r->avgf = avg_frozen;
+					}
+				} else if (vstep == vbase) {
+					if (ln == 0) {
+						WhbStepRec r;
+						r.below = 0ull;
+						r.meta = kWhbRecPseudo | wfl;
+						r.avgf = 0;
+						recrow[vstep] = r;
+					}
+					vstep++;
+				}
+			}
+		}
+		if (!EXACT && ln == 0) {
+			WhbStepRec r;
+			r.below = 0ull;
+			r.meta = kWhbRecEnd;
+			r.avgf = 0;
+			recrow[vstep] = r;
 		}
 		if (ln == 0) {
 			const uint32_t lw = drow[M - 1];
@@ -2721,6 +2766,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			st.iir_avg.dn2 = 0.5 * (double)fd2;
 		}
 	} else if (ln == 0) {  // no window in this submit: only the carried sample and timeout move on
+		if (!EXACT) {
+			WhbStepRec r;
+			r.below = 0ull;
+			r.meta = kWhbRecEnd;
+			r.avgf = 0;
+			T.whbrec[(size_t)s * T.whbrec_stride] = r;
+		}
 		ChainState &st = L.states[a][s];
 		const uint32_t lw = dec[(size_t)s * dec_stride + M - 1];
 		st.prev_i = (int)(int16_t)(lw & 0xffff);
@@ -2840,37 +2892,6 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 // window could tell the two apart (WinResult::last_bit, tracked by the demodulator kernel).
 // All equal (the rule): what whb_demod_kernel<false> emitted is the reference's result, and the exact filter state is
 // carried on in T.whbx.  Otherwise T.whbfail[s] is set: the stream's submit is redone by the exact kernel.
-struct WhbFilterRange {
-	const int32_t *wp;  // the window's stage-1 outputs
-	int total;          // the filter ran on samples [0, total) of the window
-	int vbase;          // its first step's record
-	int nf;             // filter steps (< 0: no more windows, 0: the window began locked)
-	int lock, avgf, wflags;
-};
-__device__ __forceinline__ WhbFilterRange whb_filter_range(const WinTables &T, int c, int jj, int count, int M,
-							   const int32_t *dvrow)
-{
-	WhbFilterRange d;
-	d.wp = dvrow;
-	d.total = d.vbase = d.avgf = d.wflags = 0;
-	d.lock = -1;
-	d.nf = -1;
-	if (jj < count) {
-		const WinResult r = T.result[(size_t)c * T.cap + jj];
-		const int og = T.open[(size_t)c * T.cap + jj];
-		const int close = T.close[(size_t)c * T.cap + jj];
-		const int n = (close < M ? close : M - 1) - og + 1;
-		d.nf = r.bitcnt;
-		d.lock = r.dmax;
-		d.avgf = r.dmin;
-		d.vbase = r.mark_lvl;
-		d.wflags = (r.last_bit ? 1 : 0) | (r.closed ? 2 : 0);
-		d.total = d.lock >= 0 ? d.lock + 1 : (n < 64 * d.nf ? n : 64 * d.nf);
-		d.wp = dvrow + (size_t)win_slot0(og, jj) * 32;
-	}
-	return d;
-}
-
 template <int N>
 __device__ __forceinline__ int row_ror_i32(int v)  // lane i of a row <- lane (i - N) & 15 of the same row
 {
@@ -2886,15 +2907,26 @@ __device__ __forceinline__ double row_pick_f64(double v, int src)
 	return __hiloint2double(row_pick_i32(__double2hiint(v), src), row_pick_i32(__double2loint(v), src));
 }
 
+// The walk is FLAT: whb_demod_kernel<false> leaves one WhbStepRec per filtered step, in order, with the position of the
+// step's stage-1 outputs in it (plus a record per window that never ran the filter and an end mark), so a row's loads are
+// independent of the window structure and are queued kVerAhead steps ahead (records twice as far): inside the batch the
+// kernel used to spend a third of its time waiting for the ONE step it had in flight (6.2 ms against 4.2 ms alone).
+#ifndef TFREC_AMD_VER_AHEAD
+#define TFREC_AMD_VER_AHEAD 2
+#endif
+constexpr int kVerAhead = TFREC_AMD_VER_AHEAD;  // steps whose stage-1 outputs are in flight
+constexpr int kVerRecAhead = 2 * kVerAhead;  // records in flight (a step's loads need its record)
+static_assert(kVerRecAhead + 1 <= kWhbRecSlack, "the record prefetch stays inside the row's slack");
+
 __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(const int32_t *__restrict__ dev32, int n_streams, int n_blocks,
 							ChainLaunch L, int a, WinTables T, int *__restrict__ carry_io)
 {
+	// Wave priority 0: with its loads queued ahead the check no longer sits out memory latency, it issues at the full rate
+	// of its dependent chain (two thirds of a SIMD's vector cycles).  At priority 1 the waves of the other chains that share
+	// its 256 SIMDs fell behind, and their kernels end with their slowest wave: the batch 3 % longer (profiles/r04_ab_verify.txt).
 #ifdef TFREC_AMD_VERIFY_PRIO
 	__builtin_amdgcn_s_setprio(TFREC_AMD_VERIFY_PRIO);
-#else
-	__builtin_amdgcn_s_setprio(TFREC_AMD_LAT_PRIO > 1 ? TFREC_AMD_LAT_PRIO : 1);
 #endif
-	const int M = n_blocks * kBlockDec;
 	// Workgroups of FOUR waves (independent: no barrier, no shared memory): a workgroup lands on one CU, a wave on each of
 	// its SIMDs.  As 256 one-wave workgroups the check sat on ONE SIMD of every CU of the chip, and the four-wave workgroups
 	// of the front end and the discriminator pass ran at the pace of their wave on that SIMD.
@@ -2902,12 +2934,11 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 	const int s = (blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 4 + row;
 	const bool active = s < n_streams;
 	const int sc_ = active ? s : 0;
-	const int c = a * n_streams + sc_;
 	const ChainParams &p = L.params[a];
 	const double a1 = p.iir_avg.a1, a2 = p.iir_avg.a2, bh = 0.5 * p.iir_avg.b0;
-	const int32_t *dvrow = dev32 + (size_t)sc_ * T.slots * 32;
-	const unsigned long long *recrow = T.whbrec + (size_t)sc_ * T.whbrec_stride;
-	const int count = active ? T.count[c] : 0;
+	const int32_t *dvrow = dev32 + (size_t)sc_ * T.slots * 32 + li;
+	const uint4 *recrow = reinterpret_cast<const uint4 *>(T.whbrec + (size_t)sc_ * T.whbrec_stride);
+	const uint32_t max_slot = (uint32_t)T.slots - 2u;  // (records past the end mark hold anything: their loads stay inside the row)
 	WhbExact st = T.whbx[sc_];
 	double y1 = st.y1, y2 = st.y2;
 	int fd1 = st.fd1, fd2 = st.fd2;
@@ -2915,116 +2946,122 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 	const int carry_in = carry;
 	const int tol = T.whb_test_perturb > 1 ? T.whb_test_perturb : (T.whb_test_perturb < -1 ? -T.whb_test_perturb : 1);
 	bool bad = false, done = !active;
-	// the NEXT window's range is fetched while this one is filtered
-	WhbFilterRange nxt = whb_filter_range(T, c, 0, count, M, dvrow), cur = nxt;
-	int j = -1, i = 0, nsteps = 0;
-	bool have_a = false;  // dA already holds the first step of the window about to start
-	int dA[4] = { 0, 0, 0, 0 }, dB[4] = { 0, 0, 0, 0 };  // the lane's samples 16 q + li of this step / the next
-	auto load4 = [&](int (&buf)[4], const int32_t *src) {
+	// ---- the rings: R[k] = record of step v + k, D[k][q] = the lane's samples 16 q + li of step v + k
+	uint4 R[kVerRecAhead + 1];
+	int D[kVerAhead + 1][4];
+	auto samples_of = [&](const uint4 &r, int (&buf)[4]) {
+		uint32_t slot = r.z & kWhbRecOffMask;
+		slot = slot < max_slot ? slot : max_slot;
+		const int32_t *src = dvrow + (size_t)slot * 32;
 #pragma unroll
 		for (int q = 0; q < 4; q++)
-			buf[q] = src[16 * q + li];
+			buf[q] = src[16 * q];
 	};
+#pragma unroll
+	for (int k = 0; k <= kVerRecAhead; k++)
+		R[k] = recrow[k];
+#pragma unroll
+	for (int k = 0; k <= kVerAhead; k++)
+		samples_of(R[k], D[k]);
+	int v = 0;
 	while (true) {
-		while (!done && i >= nsteps) {  // the row's next window in which the filter ran
-			cur = nxt;
-			j++;
-			if (cur.nf < 0) {
-				done = true;
-				break;
-			}
-			nxt = whb_filter_range(T, c, j + 1, count, M, dvrow);
-			i = 0;
-			nsteps = 0;
-			if (cur.nf == 0) {  // the window began locked (it continues one of the previous submit): no filter step
-				bad = bad || (carry != 0 && (cur.wflags & 1));
-				if (cur.wflags & 2)
-					carry = 0;
-				have_a = false;
-				continue;
-			}
-			nsteps = (cur.total + 63) >> 6;
-			if (!have_a)
-				load4(dA, cur.wp);
-			have_a = false;
-		}
 		if (__ballot(!done) == 0ull)
 			break;
 		if (!done) {
-			if (i + 1 < nsteps) {
-				load4(dB, cur.wp + 64 * (i + 1));
-			} else if (nxt.nf > 0) {  // the window's last step: the next window's first is fetched meanwhile
-				load4(dB, nxt.wp);
-				have_a = true;
-			}
-			const int nv = cur.total - 64 * i < 64 ? cur.total - 64 * i : 64;
-			// ---- feed-forward half of iir2::step for the lane's four samples (iir_step_t, dsp_dev.h): sample 16 q + li has
-			// its predecessors in lanes li - 1, li - 2 of set q, or in the last lanes of set q - 1 (the filter's own input
-			// history fd1, fd2 before the step's first sample)
-			double P[4], B2[4];
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const int r1 = row_ror_i32<1>(dA[q]), r2 = row_ror_i32<2>(dA[q]);
-				const int e1 = q == 0 ? fd1 : row_ror_i32<1>(dA[q > 0 ? q - 1 : 0]);  // lane 15 of the set before, in lane 0
-				const int e2 = q == 0 ? (li == 0 ? fd2 : fd1) : row_ror_i32<2>(dA[q > 0 ? q - 1 : 0]);  // its lanes 14, 15 in lanes 0, 1
-				const int p1 = li == 0 ? e1 : r1;
-				const int p2 = li < 2 ? e2 : r2;
-				const double t0 = bh * (double)dA[q], t1 = bh * (double)p1;
-				P[q] = __builtin_fma(2.0, t1, t0);
-				B2[q] = bh * (double)p2;
-			}
-			// ---- the chain, 4 x 16 samples (whb_chain_asm.h): Y3 = y(-1), Y2 = y(-2) on entry, y(63), y(62) on exit; y of
-			// the lane's sample 16 q + li is captured in Z[q][li & 3]
-			double Y0 = 0.0, Y1 = 0.0, Y2 = y2, Y3 = y1, tt, tq, ym[4];
-			const double y1_in = y1;
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				double z0, z1, z2, z3;
-				asm volatile(TFREC_WHB_CHAIN16_ASM
-					     : [Y0] "+v"(Y0), [Y1] "+v"(Y1), [Y2] "+v"(Y2), [Y3] "+v"(Y3), [Z0] "=&v"(z0), [Z1] "=&v"(z1),
-					       [Z2] "=&v"(z2), [Z3] "=&v"(z3), [T] "=&v"(tt), [Q] "=&v"(tq)
-					     : [a1] "s"(a1), [a2] "s"(a2), [ONE] "v"(1.0), [P] "v"(P[q]), [B] "v"(B2[q]));
-				const int zq = li & 3;
-				ym[q] = zq == 0 ? z0 : (zq == 1 ? z1 : (zq == 2 ? z2 : z3));
-			}
-			// ---- whb.cpp:654 "(int)", :662 "dev < avg_of": the row's 64 decisions against the recorded ones
-			unsigned long long word = 0;
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const unsigned long long b = __ballot(16 * q + li < nv && dA[q] < (int)ym[q]);
-				word |= ((b >> (16 * row)) & 0xffffull) << (16 * q);
-			}
-			const unsigned long long vm = nv >= 64 ? ~0ull : (1ull << nv) - 1ull;
-			bad = bad || ((word ^ recrow[cur.vbase + i]) & vm) != 0ull;
-			// ---- the filter's state after the step's last sample (nv - 1: a window's last step may be partial, and a lock
-			// ends the filter's run at that sample)
-			if (nv == 64) {
-				y1 = Y3;
-				y2 = Y2;
-				fd1 = __builtin_amdgcn_update_dpp(0, dA[3], 0x150 + 15, 0xf, 0xf, true);  // row_newbcast:15
-				fd2 = __builtin_amdgcn_update_dpp(0, dA[3], 0x150 + 14, 0xf, 0xf, true);
+			const uint4 rec = R[0];
+			const uint32_t meta = rec.z;
+			// the loads of the steps ahead, before this step's arithmetic
+			const uint4 rnew = recrow[v + kVerRecAhead + 1];
+			int dnew[4];
+			samples_of(R[kVerAhead + 1], dnew);
+			if (meta == kWhbRecEnd) {
+				done = true;
+			} else if (meta & kWhbRecPseudo) {  // the window began locked (it continues one of the previous submit): no filter step
+				bad = bad || (carry != 0 && (meta & kWhbRecAmb));
+				if (meta & kWhbRecClosed)
+					carry = 0;
 			} else {
-				const int pe = nv - 1, pq = pe >> 4, pb = pe > 0 ? pe - 1 : 0, pbq = pb >> 4;
-				const double ye = pq == 0 ? ym[0] : (pq == 1 ? ym[1] : (pq == 2 ? ym[2] : ym[3]));
-				const double yb = pbq == 0 ? ym[0] : (pbq == 1 ? ym[1] : (pbq == 2 ? ym[2] : ym[3]));
-				const int de = pq == 0 ? dA[0] : (pq == 1 ? dA[1] : (pq == 2 ? dA[2] : dA[3]));
-				const int db = pbq == 0 ? dA[0] : (pbq == 1 ? dA[1] : (pbq == 2 ? dA[2] : dA[3]));
-				const double yl = row_pick_f64(ye, pe & 15), ylb = row_pick_f64(yb, pb & 15);
-				const int dl = row_pick_i32(de, pe & 15), dlb = row_pick_i32(db, pb & 15);
-				y2 = pe > 0 ? ylb : y1_in;
-				y1 = yl;
-				fd2 = pe > 0 ? dlb : fd1;
-				fd1 = dl;
+				const int nv = (int)((meta >> kWhbRecNvShift) & 63u) + 1;
+				const int(&dA)[4] = D[0];
+				// ---- feed-forward half of iir2::step for the lane's four samples (iir_step_t, dsp_dev.h): sample 16 q + li has
+				// its predecessors in lanes li - 1, li - 2 of set q, or in the last lanes of set q - 1 (the filter's own input
+				// history fd1, fd2 before the step's first sample)
+				double P[4], B2[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const int r1 = row_ror_i32<1>(dA[q]), r2 = row_ror_i32<2>(dA[q]);
+					const int e1 = q == 0 ? fd1 : row_ror_i32<1>(dA[q > 0 ? q - 1 : 0]);  // lane 15 of the set before, in lane 0
+					const int e2 = q == 0 ? (li == 0 ? fd2 : fd1) : row_ror_i32<2>(dA[q > 0 ? q - 1 : 0]);  // its lanes 14, 15 in lanes 0, 1
+					const int p1 = li == 0 ? e1 : r1;
+					const int p2 = li < 2 ? e2 : r2;
+					const double t0 = bh * (double)dA[q], t1 = bh * (double)p1;
+					P[q] = __builtin_fma(2.0, t1, t0);
+					B2[q] = bh * (double)p2;
+				}
+				// ---- the chain, 4 x 16 samples (whb_chain_asm.h): Y3 = y(-1), Y2 = y(-2) on entry, y(63), y(62) on exit; y of
+				// the lane's sample 16 q + li is captured in Z[q][li & 3]
+				double Y0 = 0.0, Y1 = 0.0, Y2 = y2, Y3 = y1, tt, tq, ym[4];
+				const double y1_in = y1;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					double z0, z1, z2, z3;
+					asm volatile(TFREC_WHB_CHAIN16_ASM
+						     : [Y0] "+v"(Y0), [Y1] "+v"(Y1), [Y2] "+v"(Y2), [Y3] "+v"(Y3), [Z0] "=&v"(z0), [Z1] "=&v"(z1),
+						       [Z2] "=&v"(z2), [Z3] "=&v"(z3), [T] "=&v"(tt), [Q] "=&v"(tq)
+						     : [a1] "s"(a1), [a2] "s"(a2), [ONE] "v"(1.0), [P] "v"(P[q]), [B] "v"(B2[q]));
+					const int zq = li & 3;
+					ym[q] = zq == 0 ? z0 : (zq == 1 ? z1 : (zq == 2 ? z2 : z3));
+				}
+				// ---- whb.cpp:654 "(int)", :662 "dev < avg_of": the row's 64 decisions against the recorded ones
+				unsigned long long word = 0;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const unsigned long long b = __ballot(16 * q + li < nv && dA[q] < (int)ym[q]);
+					word |= ((b >> (16 * row)) & 0xffffull) << (16 * q);
+				}
+				const unsigned long long vm = nv >= 64 ? ~0ull : (1ull << nv) - 1ull;
+				const unsigned long long below = ((unsigned long long)rec.y << 32) | rec.x;
+				bad = bad || ((word ^ below) & vm) != 0ull;
+				// ---- the filter's state after the step's last sample (nv - 1: a window's last step may be partial, and a lock
+				// ends the filter's run at that sample)
+				if (nv == 64) {
+					y1 = Y3;
+					y2 = Y2;
+					fd1 = __builtin_amdgcn_update_dpp(0, dA[3], 0x150 + 15, 0xf, 0xf, true);  // row_newbcast:15
+					fd2 = __builtin_amdgcn_update_dpp(0, dA[3], 0x150 + 14, 0xf, 0xf, true);
+				} else {
+					const int pe = nv - 1, pq = pe >> 4, pb = pe > 0 ? pe - 1 : 0, pbq = pb >> 4;
+					const double ye = pq == 0 ? ym[0] : (pq == 1 ? ym[1] : (pq == 2 ? ym[2] : ym[3]));
+					const double yb = pbq == 0 ? ym[0] : (pbq == 1 ? ym[1] : (pbq == 2 ? ym[2] : ym[3]));
+					const int de = pq == 0 ? dA[0] : (pq == 1 ? dA[1] : (pq == 2 ? dA[2] : dA[3]));
+					const int db = pbq == 0 ? dA[0] : (pbq == 1 ? dA[1] : (pbq == 2 ? dA[2] : dA[3]));
+					const double yl = row_pick_f64(ye, pe & 15), ylb = row_pick_f64(yb, pb & 15);
+					const int dl = row_pick_i32(de, pe & 15), dlb = row_pick_i32(db, pb & 15);
+					y2 = pe > 0 ? ylb : y1_in;
+					y1 = yl;
+					fd2 = pe > 0 ? dlb : fd1;
+					fd1 = dl;
+				}
+				if (meta & kWhbRecLock) {  // the decoder locked on this sample: the average it froze (whb.cpp:653-654)
+					const int delta = (int)y1 - (int)rec.w;
+					bad = bad || delta > tol || delta < -tol || (delta != 0 && (meta & kWhbRecAmb));
+					carry = (meta & kWhbRecClosed) ? 0 : delta;
+				}
 			}
-			i++;
-			if (i >= nsteps && cur.lock >= 0) {  // the decoder locked on this sample: the average it froze (whb.cpp:653-654)
-				const int delta = (int)y1 - cur.avgf;
-				bad = bad || delta > tol || delta < -tol || (delta != 0 && (cur.wflags & 1));
-				carry = (cur.wflags & 2) ? 0 : delta;
-			}
+			// ---- the rings move on
+#pragma unroll
+			for (int k = 0; k < kVerRecAhead; k++)
+				R[k] = R[k + 1];
+			R[kVerRecAhead] = rnew;
+#pragma unroll
+			for (int k = 0; k < kVerAhead; k++)
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					D[k][q] = D[k + 1][q];
 #pragma unroll
 			for (int q = 0; q < 4; q++)
-				dA[q] = dB[q];
+				D[kVerAhead][q] = dnew[q];
+			v++;
 		}
 	}
 	if (active && li == 0) {

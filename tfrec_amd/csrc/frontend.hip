@@ -414,7 +414,7 @@ hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32
 
 // The samples fmdev_kernel flagged, decided by the exact slow path (fm_resolve.h) and logged for the host's check.
 // Launched behind every fmdev_kernel; normally nothing is pending and every workgroup returns at once.
-__global__ __launch_bounds__(256) void fm_resolve_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+__global__ __launch_bounds__(64) void fm_resolve_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							   const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
 							   size_t fmdev_stride, EventBuf *__restrict__ eb, int n_streams, int m_total,
 							   double flag_eps)
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void fm_resolve_kernel(const uint32_t *__restr
 	const uint32_t pending = eb->fm_pending;
 	if (pending == 0)
 		return;
-	const size_t nthreads = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t nthreads = (size_t)gridDim.x * 64, t0 = (size_t)blockIdx.x * 64 + threadIdx.x;
 	auto one = [&](int s, int m, bool listed) {
 		const uint32_t *drow = dec + (size_t)s * dec_stride;
 		const uint32_t w = drow[m], pw = m > 0 ? drow[m - 1] : prevdec[s];
@@ -451,7 +451,9 @@ hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, 
 	dim3 grid(m_total / kTileDec, n_streams);
 	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFrontThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
 			   fmdev_stride, eb, wmax, flag_eps);
-	hipLaunchKernelGGL(fm_resolve_kernel, dim3(128), dim3(256), 0, st, dec, dec_stride, prevdec, fmdev, fmdev_stride, eb,
+	// one-wave workgroups: the kernel normally has nothing to do, and a 256-thread workgroup waits until a CU has four
+	// wave slots and their registers free at once -- up to a millisecond on the stream that sets the batch period
+	hipLaunchKernelGGL(fm_resolve_kernel, dim3(512), dim3(64), 0, st, dec, dec_stride, prevdec, fmdev, fmdev_stride, eb,
 			   n_streams, m_total, flag_eps);
 	return hipGetLastError();
 }

@@ -158,6 +158,25 @@ struct WhbStart {
 	int32_t pad_[3];
 };
 
+// One record per 64-sample step in which whb_demod_kernel<false> ran the decision-level average (and one per window that
+// began with the decoder locked, and an end mark): everything whb_verify_kernel needs to walk a stream's submit as ONE
+// flat sequence with its loads queued several steps ahead -- where the step's stage-1 outputs are, on how many of them the
+// filter ran, the speculated decisions, and what the window froze if the decoder locked in this step.
+struct WhbStepRec {
+	unsigned long long below;  // bit k: the demodulator took "dev(k) < (int)avg(k)" (whb.cpp:662) as true
+	uint32_t meta;             // kWhbRec*: 32-sample slot of the step's first stage-1 output in the stream's dev32 row | (samples - 1) << 22 | flags
+	int32_t avgf;              // kWhbRecLock: the integer the demodulator froze (whb.cpp:653-654)
+};
+constexpr uint32_t kWhbRecOffMask = 0x3fffffu;  // offset in 32-sample slots (steps start on slot boundaries): 2^22 slots = 4096 blocks
+constexpr int kWhbRecNvShift = 22;              // 6 bits: samples of the step on which the filter ran, minus one
+constexpr uint32_t kWhbRecLock = 1u << 28;      // the decoder locked on the step's last filtered sample
+constexpr uint32_t kWhbRecAmb = 1u << 29;       // a candidate test of the window against the frozen average is ambiguous
+constexpr uint32_t kWhbRecClosed = 1u << 30;    // the window's flush fired in this submit
+constexpr uint32_t kWhbRecPseudo = 1u << 31;    // no filter step: a window that began (and stayed) locked
+constexpr uint32_t kWhbRecEnd = 0xffffffffu;    // no more records
+constexpr int kWhbRecSlack = 16;               // records whb_verify_kernel may read past the end mark (never interpreted)
+static_assert(sizeof(WhbStepRec) == 16, "one 16-byte load per record");
+
 // iir_avg of whb_demod (whb.cpp:611, 654) as whb_verify_kernel carries it: the last two outputs, bit for bit, and the
 // last two inputs (0.5 * a stage-1 output each) as the integers
 struct WhbExact {
@@ -227,8 +246,9 @@ struct WinTables {
 	                        // shared by the two table sets: the scan of submit k+1 must not wait for the chains of k)
 	// WHB stage 2, speculate + verify (chains2.hip K4'): per 64-sample step in which the decision-level average ran,
 	// the decisions "dev < (int)avg" the demodulator kernel took from its lane-parallel evaluation of the filter
-	unsigned long long *whbrec;  // [n_streams * whbrec_stride]
-	int32_t whbrec_stride;       // filter steps a stream can have in one submit (M / 64 + cap + 2)
+	WhbStepRec *whbrec;          // [n_streams * whbrec_stride], in the order whb_verify_kernel walks them
+	int32_t whbrec_stride;       // records a stream can have in one submit (filter steps M / 64 + cap, one per window that
+	                             // begins locked, the end mark) + the slack whb_verify_kernel's prefetch reads ahead
 	WhbExact *whbx;              // [n_streams] the filter's exact state, carried by whb_verify_kernel (ONE array per context)
 	int32_t *whbfail;            // [n_streams] set by whb_verify_kernel: the stream's speculation failed in this submit
 	// ... and what the exact kernel needs to do such a stream's submit again:
