@@ -87,6 +87,7 @@ struct tfrec_amd_ctx {
 	bool fmdev_k2 = false;                        // the discriminator pass runs at the head of k2, not behind the front end
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
 	hipEvent_t ev_pipe[kSets][7] = {};
+	hipStream_t fq = nullptr;                    // PipeCtl::fq (TFREC_AMD_FMDEV_OWN)
 	hipStream_t cz = nullptr;                    // PipeCtl::cz (TFREC_AMD_COOP_STREAM)                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
 	// one set per submit in flight, like the front-end outputs: the window scan and the biquads of submit k+1 fill
@@ -305,6 +306,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_tcarry);
 	if (c->cz)
 		(void)hipStreamDestroy(c->cz);
+	if (c->fq)
+		(void)hipStreamDestroy(c->fq);
 	(void)hipFree(c->d_whbx);
 	(void)hipFree(c->d_whbcarry);
 	(void)hipFree(c->d_whbgen);
@@ -691,6 +694,17 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		if (c->deep && rc == TFREC_AMD_OK && getenv("TFREC_AMD_COOP_STREAM") && atoi(getenv("TFREC_AMD_COOP_STREAM")) != 0 &&
 		    hipStreamCreateWithPriority(&c->cz, hipStreamNonBlocking, atoi(getenv("TFREC_AMD_COOP_STREAM")) == 2 ? 0 : prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
+		// The discriminator pass on a LOW-priority stream of its own (TFREC_AMD_FMDEV_OWN: 0 = at the head of k2, 1 = low
+		// (default when a WHB demodulator is registered), 2 = normal, 3 = high priority).  It needs the front end only, not
+		// the window scan; at the head of k2 it made that stream (discriminator + five biquad kernels) the one that set the
+		// batch period: 6.98 -> 6.60 ms per batch over 100 steps (profiles/r04_ab_fmdev_stream.txt).  The low-priority pool's
+		// hardware queues are otherwise unused, so the stream shares none (a fifth normal-priority stream would).
+		{
+			const int m = getenv("TFREC_AMD_FMDEV_OWN") ? atoi(getenv("TFREC_AMD_FMDEV_OWN")) : (c->fmdev_k2 ? 1 : 0);
+			if (c->deep && rc == TFREC_AMD_OK && m > 0 && c->need_fmdev && c->fmdev_k2 &&
+			    hipStreamCreateWithPriority(&c->fq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+		}
 		// whb_verify_kernel runs on the copy stream, ahead of its submit's device-to-host copies (they wait for it anyway).
 		// A stream of its own would be the FIFTH of normal priority in the process (k2, kw, cp and the caller's): it shared a
 		// hardware queue with kw, and the 6 ms verification of submit k held up the WHB biquads of submit k + 2.
@@ -811,6 +825,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.ev_kw = c->ev_pipe[set][3];
 		P.ev_fm = c->ev_pipe[set][4];
 		P.cz = c->cz;
+		P.fq = c->fq;
 		P.ev_heads = c->ev_pipe[set][5];
 		P.ev_coop = c->ev_pipe[set][6];
 		for (int k = 0; k < 3; k++)
@@ -951,7 +966,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->aux, c->vx, c->t1, c->cp })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->fq, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;

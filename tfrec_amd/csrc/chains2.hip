@@ -3618,6 +3618,16 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		TRY(hipStreamWaitEvent(P.k2, P.ev_win, 0));
 		if (fm_on_kw) {
 			TRY(hipStreamWaitEvent(P.k2, P.ev_fm, 0));
+		} else if (P.fq && P.fmdev_wmax > 0) {
+			// (TFREC_AMD_FMDEV_OWN) the discriminator pass on a stream of its own: it needs the front end only, not the window
+			// scan, and k2 -- discriminator + five biquad kernels -- is the stream that sets the period
+			TRY(hipStreamWaitEvent(P.fq, P.ev_front, 0));
+			mark(24, P.fq);
+			TRY(launch_fmdev(P.fq, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,
+					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));
+			mark(25, P.fq);
+			TRY(hipEventRecord(P.ev_fm, P.fq));
+			TRY(hipStreamWaitEvent(P.k2, P.ev_fm, 0));
 		} else if (P.fmdev_wmax > 0 && !(skip & 64)) {
 			mark(24, P.k2);
 			TRY(launch_fmdev(P.k2, dec, dec_stride, mask, mask_stride, P.prevdec, P.fmdev_out, fmdev_stride, eb, n_streams,

@@ -288,11 +288,18 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 // (oracle/tfrec_oracle.c: orc_decim10) in the reference's FIR style: 60 int16 taps (Hamming-windowed sinc, cut-off
 // 768 kHz, unity DC gain), arithmetic >>16 per tap, int16 store, 10:1:
 //   y[m] = int16( sum_{n<60} ( x[10 m - 50 + n] * h[n] ) >> 16 ),  x = (u8 - 128) << 6   (so (x*h)>>16 = ((u8-128)*h)>>10)
-// One 256-thread workgroup per tile of 1024 outputs: the tile's 20 KiB of raw bytes + 112 B of history are staged
-// into LDS with coalesced 16-byte loads (10x the bytes per output of the standard front end: this is the stage
-// that streams HBM); a lane makes 4 consecutive outputs of both rails from 180 LDS bytes.
-constexpr int kT10 = 1024;
-constexpr int kTail10 = 112;  // 56 complex samples of history (50 needed), 16-byte multiple
+// This is the stage that streams HBM (10x the bytes per output of the standard front end) and it is 87 % of the config's
+// front-end arithmetic: 60 packed FMAs per output.  A lane makes kR10 = 8 consecutive outputs of both rails from the 130
+// raw complex samples they span, read straight from global memory with unaligned 16-byte loads (neighbouring lanes
+// overlap by 50 samples: the overlap is served by the L1) -- no LDS, no barrier.  Round 3 staged the tile's raw bytes in
+// LDS and read them back a dword per lane at a lane stride of 20 dwords (bank conflicts), 4 outputs per lane (45 byte
+// conversions per output, now 32), and left the order of the FMAs to the compiler, which chained them per accumulator
+// and had to put a wait state behind two out of three (156 s_nop for 240 FMAs): here a sample's FMAs go to different
+// accumulators back to back.
+constexpr int kR10 = 8;                 // outputs per lane
+constexpr int kT10 = 256 * kR10;        // outputs per workgroup
+constexpr int kTail10 = 112;            // 56 complex samples of history (50 needed), 16-byte multiple
+constexpr int kD10 = (2 * (60 + 10 * (kR10 - 1)) + 3) / 4;  // raw dwords a lane reads: 130 complex samples = 65 dwords
 __device__ __constant__ const int kTaps10[60] = {
 	9,    27,   48,   72,   98,   121,  135,  132,  104,  44,   -53,  -185, -343, -511, -668,
 	-783, -826, -765, -572, -230, 269,  916,  1690, 2552, 3452, 4333, 5133, 5793, 6265, 6512,
@@ -304,65 +311,82 @@ __global__ __launch_bounds__(256) void decim10_kernel(const uint8_t *__restrict_
 						      const uint8_t *__restrict__ tail_in, uint8_t *__restrict__ tail_out,
 						      uint32_t *__restrict__ out, size_t out_stride)
 {
-	constexpr int kChunks = (kTail10 + 20 * kT10) / 16;
-	__shared__ __attribute__((aligned(16))) uint8_t raw[kChunks * 16];
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-	const long m0 = (long)tile * kT10;
-	__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);  // fp32 rounding toward -inf (see below)
+	const long m = (long)tile * kT10 + (long)kR10 * tid;  // the lane's first output
+	__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);  // fp32 rounding toward -inf (see frontend_kernel, stage 1)
 	const long nbytes = 20L * n_out;
 	const uint8_t *src = iq + (size_t)s * stride;
-	// raw bytes [20*m0 - 112, 20*m0 + 20*T): LDS complex sample c <-> input sample 10*m0 - 56 + c
-	const long base = 20L * m0 - kTail10;
-	for (int c = tid; c < kChunks; c += 256) {
-		const long bo = base + 16L * c;
-		uint4 v;
-		if (bo >= 0)
-			v = *reinterpret_cast<const uint4 *>(src + bo);
-		else
-			v = *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTail10 + (kTail10 + bo));
-		*reinterpret_cast<uint4 *>(raw + 16 * c) = v;
-	}
 	if (tile == (int)gridDim.x - 1 && tid < kTail10 / 16)
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail10 + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTail10 + 16 * tid);
-	__syncthreads();
-	// outputs m0 + 4*tid + o: x[10 m - 50 + n] is LDS sample 10*(4*tid + o) + 6 + n -> 90 samples from 40*tid + 6
-	const uint32_t *rp = reinterpret_cast<const uint32_t *>(raw + 2 * (40 * tid + 6));
+	if (m >= n_out)
+		return;
+	// raw complex samples [10 m - 50, 10 m + 10 kR10): bytes from 20 m - 100 (dword aligned), never past the stream's end;
+	// only the submit's first lane reaches back into the previous submit's tail
+	const long b0 = 20L * m - 100;
+	uint32_t rp[kD10];
+	if (b0 >= 0) {
+		const u32x4_u *g = reinterpret_cast<const u32x4_u *>(src + b0);
+#pragma unroll
+		for (int q = 0; q < kD10 / 4; q++) {
+			const u32x4_u v = g[q];
+			rp[4 * q] = v.x; rp[4 * q + 1] = v.y; rp[4 * q + 2] = v.z; rp[4 * q + 3] = v.w;
+		}
+#pragma unroll
+		for (int q = 4 * (kD10 / 4); q < kD10; q++)
+			rp[q] = reinterpret_cast<const uint32_t *>(src + b0)[q];
+	} else {
+#pragma unroll
+		for (int q = 0; q < kD10; q++) {
+			const long bo = b0 + 4 * q;
+			rp[q] = bo >= 0 ? *reinterpret_cast<const uint32_t *>(src + bo)
+					: *reinterpret_cast<const uint32_t *>(tail_in + (size_t)s * kTail10 + (kTail10 + bo));
+		}
+	}
 	// (d*h) >> 10 per tap as one fp32 FMA in round-toward-minus-infinity mode, both rails per v_pk_fma_f32: see stage 1 of
 	// frontend_kernel.  The 60 taps' terms sum to less than 2^14.
 	typedef float f32x2 __attribute__((ext_vector_type(2)));
 	const float kMagic = 12582912.0f;  // 2^23 + 2^22
-	f32x2 acc[4] = { { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic } };
+	f32x2 acc[kR10];
 #pragma unroll
-	for (int w = 0; w < 45; w++) {  // one dword = two complex samples
+	for (int o = 0; o < kR10; o++)
+		acc[o] = f32x2{ kMagic, kMagic };
+#pragma unroll
+	for (int w = 0; w < kD10; w++) {  // one dword = two complex samples
 		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
 		const f32x2 x[2] = { f32x2{ (float)(signed char)(v), (float)(signed char)(v >> 8) },
 				     f32x2{ (float)(signed char)(v >> 16), (float)((int)v >> 24) } };
 #pragma unroll
 		for (int h = 0; h < 2; h++) {
-			const int c = 2 * w + h;  // sample index relative to 40*tid + 6
+			const int c = 2 * w + h;  // sample index relative to 10 m - 50
 #pragma unroll
-			for (int o = 0; o < 4; o++) {
+			for (int o = 0; o < kR10; o++) {
 				const int n = c - 10 * o;
 				if (n >= 0 && n < 60) {
 					const float hs = (float)kTaps10[n] * (1.0f / 1024.0f);
 					acc[o] = __builtin_elementwise_fma(x[h], f32x2{ hs, hs }, acc[o]);
 				}
 			}
+			// the (up to six) FMAs of one sample go to different accumulators: none waits for the one before it.  Left to
+			// itself the scheduler chains the FMAs of an accumulator and pays a wait state for each
+			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
-	uint32_t ow[4];
+	uint32_t ow[kR10];
 #pragma unroll
-	for (int o = 0; o < 4; o++)  // the int16 store: the low half of the accumulator's mantissa
+	for (int o = 0; o < kR10; o++)  // the int16 store: the low half of the accumulator's mantissa
 		ow[o] = (__float_as_uint(acc[o].x) & 0xffffu) | (__float_as_uint(acc[o].y) << 16);
-	*reinterpret_cast<uint4 *>(out + (size_t)s * out_stride + m0 + 4 * tid) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)s * out_stride + m);
+#pragma unroll
+	for (int q = 0; q < kR10 / 4; q++)
+		dst[q] = make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]);
 }
 
 hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int n_streams, int n_blocks,
 			  const uint8_t *tail_in, uint8_t *tail_out, uint32_t *out, size_t out_stride)
 {
 	const long n_out = (long)n_blocks * (TFREC_AMD_BLOCK_BYTES / 2);  // complex samples at 1.536 MS/s
-	dim3 grid((unsigned)(n_out / kT10), n_streams);
+	dim3 grid((unsigned)((n_out + kT10 - 1) / kT10), n_streams);
 	hipLaunchKernelGGL(decim10_kernel, grid, dim3(256), 0, st, iq, stride, n_out, tail_in, tail_out, out, out_stride);
 	return hipGetLastError();
 }

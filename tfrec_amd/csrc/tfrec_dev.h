@@ -291,6 +291,7 @@ struct PipeCtl {
 	// TFA_2 family, stage B split: once the long windows' heads are sliced (cs), the cooperative slicers of their tails
 	// run on cz beside the short windows' slicers on cs (nullptr: one after the other on cs)
 	hipStream_t cz;
+	hipStream_t fq;            // the discriminator pass's own stream (TFREC_AMD_FMDEV_OWN), or nullptr: at the head of k2
 	hipEvent_t ev_heads, ev_coop;
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
 	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
