@@ -472,7 +472,9 @@ def main():
 
         try:
             side("configs[1]: one 1.536 MS/s stream, TFA_1/2/3 (-T 7)", 1, 48, 0x07, False, 30)
-            side("configs[4]: 256 streams at 15.36 MS/s through the 10:1 front end, all five protocols", 256, 48, 0x2F, True, 8)
+            # (512 streams: 16 GB of input per batch -- with 256 the 10:1 stage hides behind the demodulator chains, whose length
+            # does not shrink with the batch; BASELINE.json names no stream count for this configuration)
+            side("configs[4]: 512 streams at 15.36 MS/s through the 10:1 front end, all five protocols", 512, 48, 0x2F, True, 8)
             # the streaming kernels without the WHB chain's serial floor: configs[2]'s batch with the demodulators of configs[1]
             side("1024 streams x TFA_1/2/3 (-T 7): no WHB chain", 1024, 48, 0x07, False, 12)
         except Exception as e:  # informative legs: never fail the line for them

@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (GPU box, repo root): profiles/run_round3.sh <tag>  -> gpurun_out/<tag>_* (copy what is to be kept into profiles/)
+# usage (GPU box, repo root): profiles/run_round.sh <tag>  -> gpurun_out/<tag>_* (copy what is to be kept into profiles/)
 # bench line, kernel trace + stats of the same command, steady-state timeline, PMC passes (each in its own run, counters
 # only: no trace domains), HBM traffic, VALU mix + measured issue costs -> the VALU roof.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-r03}
+tag=${1:-r04}
 cd /tmp
 python $R/bench.py > $R/gpurun_out/${tag}_bench.json 2> $R/gpurun_out/${tag}_bench.err
 python $R/bench.py --steps 200 --cpu-budget 0 --h2d-steps 0 --no-extra-configs --parity-streams 64 > $R/gpurun_out/${tag}_bench_200steps.json 2>/dev/null
