@@ -620,6 +620,7 @@ def main():
                 "gpu_ms_per_step": round(float(np.mean(kt.get("total_ms", [0.0]))), 4),
                 "speculation_stats": r.stats(),
                 "pipeline_streams": r.layout(),
+                "context_memory": r.memory(),
             },
         }
         if a.cpu_budget > 0 and world == 1 and rate == 1:

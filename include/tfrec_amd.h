@@ -223,6 +223,10 @@ int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
  * created), 2 = the serial cross-check (TFREC_AMD_F_SERIAL_CHAINS).  Results do not depend on it.  No reference
  * counterpart. */
 int tfrec_amd_get_layout(tfrec_amd_ctx *ctx, int *n_streams);
+/* Device memory the context holds (front-end outputs, window tables, biquad outputs, state, event buffers: one set per
+ * submit that may be in flight) and the page-locked host memory of its drain buffers, in bytes.  The caller's input
+ * batches are not counted.  No reference counterpart. */
+int tfrec_amd_get_memory(tfrec_amd_ctx *ctx, uint64_t *device_bytes, uint64_t *pinned_host_bytes);
 /* Current trigger threshold of one stream (auto mode, fm_demod.cpp:58-73, moves it; fixed mode returns cfg.thresh). */
 int tfrec_amd_read_thresh(tfrec_amd_ctx *ctx, int stream, int *thresh);
 

@@ -89,7 +89,7 @@ EXPORTS = (
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
     "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_get_layout", "tfrec_amd_host_alloc",
     "tfrec_amd_host_free", "tfrec_amd_read_stage0", "tfrec_amd_get_fm_stats", "tfrec_amd_fm_dev_probe",
-    "tfrec_amd_fifo_depth",
+    "tfrec_amd_fifo_depth", "tfrec_amd_get_memory",
 )
 
 _lib = None
@@ -140,6 +140,7 @@ def load_library(build: bool = True):
     L.tfrec_amd_read_thresh.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.tfrec_amd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.tfrec_amd_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.tfrec_amd_get_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.tfrec_amd_get_fm_stats.argtypes = [C.c_void_p, C.POINTER(FmStats)]
     L.tfrec_amd_fm_dev_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(FmStats)]
     L.tfrec_amd_fifo_depth.restype = C.c_int
@@ -267,6 +268,12 @@ class Receiver:
         n = C.c_int(0)
         _check(self.L, self.L.tfrec_amd_get_layout(self.h, C.byref(n)))
         return int(n.value)
+
+    def memory(self) -> dict:
+        """Bytes of device memory / page-locked host memory the context holds (the caller's input batches not counted)."""
+        d, h = C.c_uint64(), C.c_uint64()
+        _check(self.L, self.L.tfrec_amd_get_memory(self.h, C.byref(d), C.byref(h)))
+        return {"device_bytes": int(d.value), "pinned_host_bytes": int(h.value)}
 
     def stats(self) -> dict:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""

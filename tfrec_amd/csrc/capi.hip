@@ -156,6 +156,7 @@ struct tfrec_amd_ctx {
 	// state, the FIFO's bookkeeping), so the context cannot continue exactly.  Every later submit / drain returns
 	// TFREC_AMD_E_STATE; destroy and recreate.
 	bool poisoned = false;
+	size_t dev_bytes = 0, pinned_bytes = 0;  // tfrec_amd_get_memory
 	// TFREC_AMD_HOST_PROF=1: host-side time of the submit / drain calls, printed when the context is destroyed
 	double hp_submit = 0, hp_wait = 0, hp_copy = 0, hp_sort = 0, hp_gap = 0, hp_lat = 0, hp_s2s = 0;
 	long hp_n = 0, hp_gap_n = 0;
@@ -412,6 +413,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		if (rc == TFREC_AMD_OK && hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { \
 			snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) failed", (size_t)(bytes)); \
 			rc = TFREC_AMD_E_NOMEM;                               \
+		} else if (rc == TFREC_AMD_OK) {                              \
+			c->dev_bytes += (size_t)(bytes);                      \
 		}                                                             \
 	} while (0)
 	for (int s = 0; s < kNSlots && rc == TFREC_AMD_OK; s++) {
@@ -621,6 +624,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			rc = TFREC_AMD_E_NOMEM;
 			break;
 		}
+		c->pinned_bytes += kEvHeader + (size_t)cfg->max_events * sizeof(tfrec_amd_event);
 		c->h_eb[k] = (EventBuf *)c->h_evblock[k];
 		c->h_events[k] = (tfrec_amd_event *)(c->h_evblock[k] + kEvHeader);
 	}
@@ -1283,6 +1287,17 @@ int tfrec_amd_get_layout(tfrec_amd_ctx *c, int *n_streams)
 	if (!c || !n_streams)
 		return TFREC_AMD_E_INVAL;
 	*n_streams = (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) ? 2 : (c->deep ? 6 : 4);
+	return TFREC_AMD_OK;
+}
+
+int tfrec_amd_get_memory(tfrec_amd_ctx *c, uint64_t *device_bytes, uint64_t *pinned_host_bytes)
+{
+	if (!c || !device_bytes || !pinned_host_bytes)
+		return TFREC_AMD_E_INVAL;
+	*device_bytes = c->dev_bytes;
+	for (size_t b : c->stage_bytes)  // staging of tfrec_amd_submit_host, grown on demand
+		*device_bytes += b;
+	*pinned_host_bytes = c->pinned_bytes;
 	return TFREC_AMD_OK;
 }
 

@@ -89,7 +89,10 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 
 	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes 4 consecutive outputs of both rails.
 	// Outputs k..k+3 need x[2k-6 .. 2k+7]: 28 raw bytes at offset base + 12 + 16*grp (k = 2*m0 - 22 + 4*grp).
-	constexpr int kGroups = (2 * kTileDec + 24 + 3) / 4;
+	// The tile needs 2*T + 24 of them: 2*T in two passes of the 256 lanes, the last 24 one per lane (below).
+	constexpr int kGroups = (2 * kTileDec) / 4;
+	static_assert(kGroups == 2 * kFrontThreads, "two full passes");
+#pragma unroll
 	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
 		uint32_t rp[7 * kB];
 		{
@@ -162,6 +165,44 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		*reinterpret_cast<f32x4 *>(&y1[4 * grp]) = f32x4{ oy[0].x, oy[0].y, oy[1].x, oy[1].y };
 		*reinterpret_cast<f32x4 *>(&y1[4 * grp + 2]) = f32x4{ oy[2].x, oy[2].y, oy[3].x, oy[3].y };
 	}
+	// ---- ... and the 24 stage-1 outputs behind them (slots 2*T .. 2*T + 23: the far end of the tile's last stage-2
+	// windows), ONE per lane of the first 24: 8 samples = 16 raw bytes (x kB) at offset 4*slot + 12.  As a third pass of the
+	// group loop they cost wave 0 a whole group iteration for 6 busy lanes.
+	if (tid < 24) {
+		const int slot = 2 * kTileDec + tid;
+		const int off = kB * (4 * slot + 12);
+		uint32_t rp[4 * kB];
+		if (interior || (base + off >= 0 && base + off + 16 * kB <= nbytes)) {
+			const u32x4_u *g = reinterpret_cast<const u32x4_u *>(src + base + off);
+#pragma unroll
+			for (int q = 0; q < kB; q++) {
+				const u32x4_u v = g[q];
+				rp[4 * q] = v.x; rp[4 * q + 1] = v.y; rp[4 * q + 2] = v.z; rp[4 * q + 3] = v.w;
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4 * kB; q++)
+				rp[q] = raw_dword(base + off + 4 * q);
+		}
+		f32x2 acc = { kMagic, kMagic };
+		if (IN16) {
+#pragma unroll
+			for (int n = 0; n < 8; n++) {
+				const float hs = (float)kS1[n] * (1.0f / 65536.0f);
+				acc = __builtin_elementwise_fma(f32x2{ (float)(int)(int16_t)(rp[n] & 0xffff), (float)((int)rp[n] >> 16) }, f32x2{ hs, hs }, acc);
+			}
+			y1[slot] = f32x2{ (float)(int)(int16_t)(__float_as_uint(acc.x) & 0xffffu), (float)(int)(int16_t)(__float_as_uint(acc.y) & 0xffffu) };
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const uint32_t w = rp[i] ^ 0x80808080u;
+				const float h0 = (float)kS1[2 * i] * (1.0f / 1024.0f), h1 = (float)kS1[2 * i + 1] * (1.0f / 1024.0f);
+				acc = __builtin_elementwise_fma(f32x2{ (float)(signed char)(w), (float)(signed char)(w >> 8) }, f32x2{ h0, h0 }, acc);
+				acc = __builtin_elementwise_fma(f32x2{ (float)(signed char)(w >> 16), (float)((int)w >> 24) }, f32x2{ h1, h1 }, acc);
+			}
+			y1[slot] = acc - f32x2{ kMagic, kMagic };
+		}
+	}
 	__syncthreads();
 
 	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs LDS slots [8*tid + 4 + 2*o, +20).
@@ -177,19 +218,37 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		y[2 * i] = f32x2{ a.x, a.y };
 		y[2 * i + 1] = f32x2{ a.z, a.w };
 	}
-	int oI[4], oQ[4];
 	uint32_t outw[4];
-	bool trig[4];
+	uint32_t nib = 0;  // trigger bits of the lane's four samples
+	// u8 input: the sums stay below 2^14 in magnitude (|y1| <= 8526, |y2| <= 12153 with the wide taps), so the int16 store
+	// changes nothing and acc - 2^23 - 2^22 IS the sample: |I| + |Q| > thresh (fm_demod.cpp:45, tfa1.cpp:147) is evaluated on
+	// the floats -- exact integers below 2^17 --, as the sign of (thresh + 0.5) - (|I| + |Q|) (never zero: x - x would be -0
+	// in this kernel's rounding mode).  5 instructions per sample instead of 9 and no compare / select pairs with their
+	// wait states; the 16-bit halves are packed by one v_perm_b32.
+	const float thresh_h = (float)thresh + 0.5f;
+	f32x2 acc4[4] = { { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic } };
+#pragma unroll
+	for (int n = 0; n < 20; n++) {
+#pragma unroll
+		for (int o = 0; o < 4; o++)
+			acc4[o] = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc4[o]);
+		// a tap's four FMAs go to four accumulators: none waits for the one before it (chained per accumulator, a packed FMA
+		// needs a wait state before its successor)
+		__builtin_amdgcn_sched_barrier(0);
+	}
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
-		f32x2 acc = { kMagic, kMagic };
-#pragma unroll
-		for (int n = 0; n < 20; n++)
-			acc = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc);
-		oI[o] = (int)(int16_t)(__float_as_uint(acc.x) & 0xffffu);
-		oQ[o] = (int)(int16_t)(__float_as_uint(acc.y) & 0xffffu);
-		outw[o] = ((uint32_t)oI[o] & 0xffffu) | ((uint32_t)oQ[o] << 16);
-		trig[o] = (abs(oI[o]) + abs(oQ[o])) > thresh;
+		const f32x2 acc = acc4[o];
+		if (IN16) {  // int16 input: the reference's int16 store can wrap (dsp_stuff.cpp:196): integer path
+			const int oI = (int)(int16_t)(__float_as_uint(acc.x) & 0xffffu), oQ = (int)(int16_t)(__float_as_uint(acc.y) & 0xffffu);
+			outw[o] = ((uint32_t)oI & 0xffffu) | ((uint32_t)oQ << 16);
+			nib |= (uint32_t)((abs(oI) + abs(oQ)) > thresh) << o;
+		} else {
+			const f32x2 d = acc - f32x2{ kMagic, kMagic };
+			const float r = thresh_h - (__builtin_fabsf(d.x) + __builtin_fabsf(d.y));
+			nib |= (__float_as_uint(r) >> 31) << o;
+			outw[o] = __builtin_amdgcn_perm(__float_as_uint(acc.y), __float_as_uint(acc.x), 0x05040100u);
+		}
 	}
 	*reinterpret_cast<uint4 *>(dec + (size_t)s * dec_stride + m0 + 4 * tid) =
 		make_uint4(outw[0], outw[1], outw[2], outw[3]);
@@ -200,7 +259,6 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	// (Built from four ballots with bit-spreading arithmetic this was a quarter of the kernel's vector instructions.)
 	{
 		const int lane = tid & 63, wave = tid >> 6;
-		const uint32_t nib = (uint32_t)trig[0] | ((uint32_t)trig[1] << 1) | ((uint32_t)trig[2] << 2) | ((uint32_t)trig[3] << 3);
 		uint32_t v = nib << (4 * (lane & 7));
 		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
 		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
