@@ -501,7 +501,7 @@ def main():
         same_workload = (n_streams, n_blocks, a.types, rate) == (1024, 48, 0x2F, 1)
         ptag = next((t for t in ("r04_final", "r04_mid", "r03_final", "r03_mid")
                      if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
-        chain_floor = fe_alone = None
+        chain_floor = fe_alone = chain_kernel = None
         if ptag and same_workload:
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_traffic.json")))
@@ -548,7 +548,10 @@ def main():
                 # the serial floor: the dominant chain kernel ALONE on the chip (serial per stream; consecutive batches'
                 # launches of it run one after the other) and the only kernel that streams the input, alone
                 kj = vj.get("kernels", {})
-                chain_floor = kj.get(dom_name, {}).get("kernel_ms_alone")
+                # (the longest single kernel alone: the serial per-stream chains -- the WHB check, the WHB demodulator -- are
+                # launched once per batch and consecutive batches' launches run one after the other on their stream)
+                chain_floor = max((v.get("kernel_ms_alone") or 0.0) for v in kj.values()) or None
+                chain_kernel = max(kj, key=lambda k: kj[k].get("kernel_ms_alone") or 0.0) if kj else None
                 fe_alone = next((v.get("kernel_ms_alone") for k, v in kj.items() if k.startswith("frontend_kernel")), None)
             except Exception:
                 pass
@@ -608,7 +611,7 @@ def main():
                 "hbm_floor_ms": alg_bytes_ms(n_streams, n_blocks, rate),
                 "algorithmic_valu_floor_ms": alg["ms"] if alg else None,
                 "algorithmic_valu_floor": alg,
-                "chain_floor_ms": chain_floor,
+                "chain_floor_ms": chain_floor, "chain_floor_kernel": chain_kernel,
                 "period_over_max_floor": (round(period_ms / max(floors), 3) if floors else None),
                 "frontend": ({"ms_alone": fe_alone, "frac": round(alg_bytes / (fe_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "source": "profiles/%s_valu.json" % ptag} if fe_alone else None),

@@ -1,3 +1,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 900 python -m pytest tests -m gpu -x -q -k "frontend or config5 or smoke or all_flush or auto_thresh or stress or hostile or wide" 2>&1 | tail -3
-bash profiles/ab_driver.sh 2 > gpurun_out/r4_ab_fe.txt 2>&1; cat gpurun_out/r4_ab_fe.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 20 --warmup 5 --cpu-budget 0 --h2d-steps 0 --no-extra-configs 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = j['roofline']
+print(j['ms_per_step'], j['ms_per_step_steady'], r['frac'], r['kernel'], r['chain_floor_ms'], r['chain_floor_kernel'], r['period_over_max_floor'], r['frontend'], r['context_memory'], r['traffic_ratio'], r['profiles'])
+"

@@ -521,7 +521,22 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		WinTables &T = c->win[set];
 		T.cap = (int32_t)(m_max / 356 + 2);  // windows of one chain are > W-1 >= 355 samples apart
 		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
-		ALLOC(c->d_ld16[set], chains * (size_t)T.slots * 32 * sizeof(int16_t));
+		// rows only for the chains that use them: ld16 for the TFA_2 family (its slots are adjacent in registration order),
+		// checkpoints for the chains with a biquad stage (all but TFA_1, which is registered first)
+		int a_ld0 = -1, n_ld = 0, a_ck0 = -1;
+		for (int a = 0; a < c->launch.n_active; a++) {
+			if (c->launch.params[a].kind == 1) {
+				if (a_ld0 < 0)
+					a_ld0 = a;
+				n_ld = a - a_ld0 + 1;
+			}
+			if (c->launch.params[a].kind != 0 && a_ck0 < 0)
+				a_ck0 = a;
+		}
+		T.ld_c0 = (int32_t)((a_ld0 < 0 ? 0 : a_ld0) * n);
+		T.ck_c0 = (int32_t)((a_ck0 < 0 ? 0 : a_ck0) * n);
+		const size_t ck_chains = a_ck0 < 0 ? 0 : chains - (size_t)a_ck0 * n;
+		ALLOC(c->d_ld16[set], std::max<size_t>(1, (size_t)n_ld * n) * (size_t)T.slots * 32 * sizeof(int16_t));
 		if (whb)
 			ALLOC(c->d_dev32[set], n * (size_t)T.slots * 32 * sizeof(int32_t) + 4096);  // + slack: whb_demod_kernel keeps two 64-sample steps in flight past a row's last window
 		T.bit_words = (int32_t)(m_max / 64 + 3 * (size_t)T.cap + 8);
@@ -539,7 +554,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_queue = carve((kNQueues + 1) * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(128);
 		T.segcap = (int32_t)((m_max / 32 + (size_t)T.cap) / kSegSlots + 2);
 		const size_t segs = chains * (size_t)T.segcap;
-		const size_t o_ckpt = carve(chains * (size_t)T.slots * sizeof(double2));
+		const size_t o_ckpt = carve(ck_chains * (size_t)T.slots * sizeof(double2));
 		const size_t o_sstart = carve(segs * sizeof(uint2)), o_vtotal = carve(chains * 4);
 		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
 		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4);

@@ -733,8 +733,8 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 				count = T.count[c];
 				cf = L.params[a].iir;
 				in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
-				out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
-				ckrow = T.ckpt + (size_t)c * T.slots;
+				out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)(c - T.ld_c0) * T.slots * 32);
+				ckrow = T.ckpt + (size_t)(c - T.ck_c0) * T.slots;
 				prev0 = T.prevdec[s];  // not the chain state's prev_i/q: stage B of the previous submit may still be running
 				pp.j = (int)start.x;
 				pp.i = (int)start.y;
@@ -829,9 +829,9 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	const BiquadCoef cf = L.params[a].iir;
 	const BiquadEnd *e1 = T.segend1 + (size_t)c * T.segcap;
 	const void *in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
-	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)c * T.slots * 32);
+	void *out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)(c - T.ld_c0) * T.slots * 32);
 	const uint32_t prev0 = T.prevdec[s];
-	const double2 *ckrow = T.ckpt + (size_t)c * T.slots;
+	const double2 *ckrow = T.ckpt + (size_t)(c - T.ck_c0) * T.slots;
 	// the end state of segment kk, IF the last run that wrote it started from the true state
 	auto end_if_good = [&](int kk) -> BiquadEnd {
 		if (kk == 0)
@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void window_task(int c, int j, int n_streams, int M, 
 	}
 	BitWriter bw{ T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j, 0u, 0, 0u, -1 };
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)c * T.slots * 32) +
+	const uint32_t *ldslots = (KIND == 1) ? reinterpret_cast<const uint32_t *>(ld16 + (size_t)(c - T.ld_c0) * T.slots * 32) +
 							(size_t)win_slot0(og, j) * 16
 					      : nullptr;
 	const int resume = run_window<KIND>(f, bw, og, last, closed, drow, ldslots, st.prev_i, st.prev_q, p.spb, p.nb_mul, my_lds,
@@ -1439,7 +1439,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	const bool closed = close < M;
 	const int last = closed ? close : M - 1;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
-	const int16_t *ldrow = ld16 + (size_t)c * T.slots * 32 + (size_t)win_slot0(og, j) * 32;  // window-relative
+	const int16_t *ldrow = ld16 + (size_t)(c - T.ld_c0) * T.slots * 32 + (size_t)win_slot0(og, j) * 32;  // window-relative
 	// ---- wave-uniform slicer state (tfa2.h:35-42): where the lane-per-window head (slicer_kernel) stopped
 	// (fresh: the whole window from its first sample, with the given last_bit_idx -- commit's exact re-slice)
 	WinResult &rr = T.result[(size_t)c * T.cap + j];

@@ -228,7 +228,9 @@ struct WinTables {
 	                        // queue 7: peak-detector pieces of long TFA_1 windows (chain, j | p << 17)
 	WorkQueue *queue;       // [8]
 	int32_t slots;          // 32-sample slots per chain row of the window-relative arrays below
-	double2 *ckpt;          // [chains*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
+	double2 *ckpt;          // [(chains - ck_c0)*slots] (yn, yn1) after the last sample of each slot, speculative biquad run
+	int32_t ck_c0;          // first chain with a biquad stage (TFA_1, registered first, has none): rows of ckpt start there
+	int32_t ld_c0;          // first TFA_2-family chain: rows of ld16 start there (the family's slots are adjacent)
 	// biquad segments: the in-window slots of a chain, numbered consecutively across windows ("virtual slots"),
 	// are cut into segments of kSegSlots slots
 	int32_t segcap;         // segments per chain the tables can hold
