@@ -570,6 +570,8 @@ def main():
             "ms_max": round(float(step_ms.max()), 4),
             # without the steps in which the FIFO of `depth` batches fills and drains (the timed region starts and ends empty)
             "ms_per_step_steady": (round(float(step_ms[depth:-depth].mean()), 4) if len(step_ms) > 2 * depth + 2 else None),
+            # (every step of a short run: where the FIFO's filling, a late host or a slow tail went)
+            "step_ms": ([round(float(x), 3) for x in step_ms] if len(step_ms) <= 64 else None),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -88,6 +88,7 @@ struct tfrec_amd_ctx {
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
 	hipEvent_t ev_pipe[kSets][7] = {};
 	hipStream_t fq = nullptr;                    // PipeCtl::fq (TFREC_AMD_FMDEV_OWN)
+	hipStream_t cq = nullptr;                    // the drain's copies, when not on cp (TFREC_AMD_COPY_OWN)
 	hipStream_t cz = nullptr;                    // PipeCtl::cz (TFREC_AMD_COOP_STREAM)                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
 	// one set per submit in flight, like the front-end outputs: the window scan and the biquads of submit k+1 fill
@@ -309,6 +310,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipStreamDestroy(c->cz);
 	if (c->fq)
 		(void)hipStreamDestroy(c->fq);
+	if (c->cq)
+		(void)hipStreamDestroy(c->cq);
 	(void)hipFree(c->d_whbx);
 	(void)hipFree(c->d_whbcarry);
 	(void)hipFree(c->d_whbgen);
@@ -724,6 +727,13 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			    hipStreamCreateWithPriority(&c->fq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
+		// The drain's copy on a low-priority stream of its own (TFREC_AMD_COPY_OWN=0: on cp).  On cp it sat between the WHB
+		// checks of consecutive submits and waits for ALL chains of its submit: the check of submit k + 1 could not start
+		// before the TFA chains of submit k had ended.  6.32 -> 6.21 ms per batch over 100 steps
+		// (profiles/r04_ab_copy_stream.txt); the low pool's hardware queues hold only this stream and the discriminator's.
+		if (c->deep && rc == TFREC_AMD_OK && !(getenv("TFREC_AMD_COPY_OWN") && atoi(getenv("TFREC_AMD_COPY_OWN")) == 0) &&
+		    hipStreamCreateWithPriority(&c->cq, hipStreamNonBlocking, prio_lo) != hipSuccess)
+			rc = TFREC_AMD_E_HIP;
 		// whb_verify_kernel runs on the copy stream, ahead of its submit's device-to-host copies (they wait for it anyway).
 		// A stream of its own would be the FIFTH of normal priority in the process (k2, kw, cp and the caller's): it shared a
 		// hardware queue with kw, and the 6 ms verification of submit k held up the WHB biquads of submit k + 2.
@@ -900,7 +910,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		}
 	}
 	// the drain's copies, queued now
-	hipStream_t cpy = c->cp;
+	hipStream_t cpy = c->cq ? c->cq : c->cp;
 	for (auto &e : c->done[set])
 		HIPCHK(hipStreamWaitEvent(cpy, e, 0));
 	c->copied_n[set] = std::min<uint32_t>(c->copy_guess, (uint32_t)c->cfg.max_events);
@@ -985,7 +995,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->fq, c->aux, c->vx, c->t1, c->cp })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->fq, c->cq, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;
