@@ -2299,11 +2299,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 	constexpr bool redo = REDO;
 	static_assert(EXACT || !REDO, "only the exact kernel redoes a submit");
 	extern __shared__ __attribute__((aligned(16))) uint8_t rdata_lds[];  // 64 x 64 B, used by the decoder tail
-#ifdef TFREC_AMD_WHB_PRIO
-	__builtin_amdgcn_s_setprio(TFREC_AMD_WHB_PRIO);
-#else
-	latency_prio();
+	// Wave priority 1: since the check stopped being the longest kernel of the batch (round 4) this one is, and its 1024
+	// statically placed waves end with the slowest: 5.5 -> 5.1 ms inside the batch, the batch 1 % shorter
+	// (profiles/r04_ab_whb_prio.txt; priority 2: the same).
+#ifndef TFREC_AMD_WHB_PRIO
+#define TFREC_AMD_WHB_PRIO 1
 #endif
+	__builtin_amdgcn_s_setprio(TFREC_AMD_WHB_PRIO);
 	// One of these waves per SIMD, never two: the kernel claims 264 of a SIMD's 512 registers (256 + 8 accumulation
 	// registers it never touches).  Its one-wave workgroups are dispatched while the other chains' kernels fill the chip
 	// and land wherever a wave slot is free; two of them on one SIMD share its VALU (the recurrence alone wants 3/4 of
