@@ -346,18 +346,26 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 // (oracle/tfrec_oracle.c: orc_decim10) in the reference's FIR style: 60 int16 taps (Hamming-windowed sinc, cut-off
 // 768 kHz, unity DC gain), arithmetic >>16 per tap, int16 store, 10:1:
 //   y[m] = int16( sum_{n<60} ( x[10 m - 50 + n] * h[n] ) >> 16 ),  x = (u8 - 128) << 6   (so (x*h)>>16 = ((u8-128)*h)>>10)
-// This is the stage that streams HBM (10x the bytes per output of the standard front end) and it is 87 % of the config's
-// front-end arithmetic: 60 packed FMAs per output.  A lane makes kR10 = 8 consecutive outputs of both rails from the 130
-// raw complex samples they span, read straight from global memory with unaligned 16-byte loads (neighbouring lanes
-// overlap by 50 samples: the overlap is served by the L1) -- no LDS, no barrier.  Round 3 staged the tile's raw bytes in
-// LDS and read them back a dword per lane at a lane stride of 20 dwords (bank conflicts), 4 outputs per lane (45 byte
-// conversions per output, now 32), and left the order of the FMAs to the compiler, which chained them per accumulator
-// and had to put a wait state behind two out of three (156 s_nop for 240 FMAs): here a sample's FMAs go to different
-// accumulators back to back.
+// This is the stage that streams HBM (10x the bytes per output of the standard front end) and it is 87 % of the
+// configuration's front-end arithmetic: 60 packed FMAs per output.  One 128-thread workgroup per tile of 1024 outputs:
+//   * the tile's 20 KiB of raw bytes + 112 B of history are staged into LDS with COALESCED 16-byte loads.  (A lane
+//     reading its own 260 bytes straight from global memory -- round 4's first version -- touches every cache line with
+//     eight different load instructions: the kernel was bound by L1 transactions, 2.8 ms per 256 streams; 16 outputs per
+//     lane made it worse.)
+//   * a lane makes kR10 = 8 consecutive outputs of both rails from the 130 raw samples they span: lane stride 40 dwords.
+//     The LDS image has ONE pad dword behind every 40: the stride becomes 41 dwords and the 64 lanes of a read hit 64
+//     different banks (round 3 read the unpadded image: stride 20 dwords at 4 outputs per lane, an 8-way conflict).
+//   * a sample's (up to six) FMAs go to different accumulators back to back: left to itself the scheduler chains the
+//     FMAs of an accumulator and pays a wait state behind two out of three (round 3: 156 s_nop for 240 FMAs).
 constexpr int kR10 = 8;                 // outputs per lane
-constexpr int kT10 = 256 * kR10;        // outputs per workgroup
+constexpr int kT10 = 1024;              // outputs per workgroup
+constexpr int kThreads10 = kT10 / kR10; // 128
 constexpr int kTail10 = 112;            // 56 complex samples of history (50 needed), 16-byte multiple
 constexpr int kD10 = (2 * (60 + 10 * (kR10 - 1)) + 3) / 4;  // raw dwords a lane reads: 130 complex samples = 65 dwords
+constexpr int kRawDw10 = (kTail10 + 20 * kT10) / 4;          // logical dwords of a tile's LDS image (dword 0 = byte 20 m0 - 112)
+constexpr int kLaneDw10 = 20 * kR10 / 4;                     // 40: a lane's stride in logical dwords, = the pad interval
+static_assert(kLaneDw10 % 4 == 0, "a 16-byte chunk never straddles a pad");
+__device__ __forceinline__ constexpr int pad10(int d) { return d + d / kLaneDw10; }  // logical -> physical dword
 __device__ __constant__ const int kTaps10[60] = {
 	9,    27,   48,   72,   98,   121,  135,  132,  104,  44,   -53,  -185, -343, -511, -668,
 	-783, -826, -765, -572, -230, 269,  916,  1690, 2552, 3452, 4333, 5133, 5793, 6265, 6512,
@@ -365,76 +373,87 @@ __device__ __constant__ const int kTaps10[60] = {
 	-668, -511, -343, -185, -53,  44,   104,  132,  135,  121,  98,   72,   48,   27,   9,
 };
 
-__global__ __launch_bounds__(256) void decim10_kernel(const uint8_t *__restrict__ iq, size_t stride, long n_out,
-						      const uint8_t *__restrict__ tail_in, uint8_t *__restrict__ tail_out,
-						      uint32_t *__restrict__ out, size_t out_stride)
+__global__ __launch_bounds__(kThreads10) void decim10_kernel(const uint8_t *__restrict__ iq, size_t stride, long n_out,
+							     const uint8_t *__restrict__ tail_in, uint8_t *__restrict__ tail_out,
+							     uint32_t *__restrict__ out, size_t out_stride)
 {
+	__shared__ uint32_t raw[pad10(kRawDw10) + 4];
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-	const long m = (long)tile * kT10 + (long)kR10 * tid;  // the lane's first output
+	const long m0 = (long)tile * kT10;
 	__builtin_amdgcn_s_setreg(1 | (0 << 6) | (1 << 11), 2);  // fp32 rounding toward -inf (see frontend_kernel, stage 1)
 	const long nbytes = 20L * n_out;
 	const uint8_t *src = iq + (size_t)s * stride;
+	// ---- stage the tile: chunk c = logical dwords 4c .. 4c + 3 = stream bytes 20 m0 - 112 + 16 c ..; the submit's first
+	// tile takes its first seven chunks from the previous submit's tail
+	const long base = 20L * m0 - kTail10;
+	constexpr int kChunks = kRawDw10 / 4;
+#pragma unroll
+	for (int c0 = 0; c0 < kChunks; c0 += kThreads10) {
+		const int c = c0 + tid;
+		if (c0 + kThreads10 <= kChunks || c < kChunks) {
+			const long bo = base + 16L * c;
+			const uint4 v = bo >= 0 ? *reinterpret_cast<const uint4 *>(src + bo)
+						: *reinterpret_cast<const uint4 *>(tail_in + (size_t)s * kTail10 + (kTail10 + bo));
+			uint32_t *d = raw + 4 * c + c / (kLaneDw10 / 4);
+			d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+		}
+	}
 	if (tile == (int)gridDim.x - 1 && tid < kTail10 / 16)
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail10 + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTail10 + 16 * tid);
-	if (m >= n_out)
-		return;
-	// raw complex samples [10 m - 50, 10 m + 10 kR10): bytes from 20 m - 100 (dword aligned), never past the stream's end;
-	// only the submit's first lane reaches back into the previous submit's tail
-	const long b0 = 20L * m - 100;
-	uint32_t rp[kD10];
-	if (b0 >= 0) {
-		const u32x4_u *g = reinterpret_cast<const u32x4_u *>(src + b0);
-#pragma unroll
-		for (int q = 0; q < kD10 / 4; q++) {
-			const u32x4_u v = g[q];
-			rp[4 * q] = v.x; rp[4 * q + 1] = v.y; rp[4 * q + 2] = v.z; rp[4 * q + 3] = v.w;
-		}
-#pragma unroll
-		for (int q = 4 * (kD10 / 4); q < kD10; q++)
-			rp[q] = reinterpret_cast<const uint32_t *>(src + b0)[q];
-	} else {
-#pragma unroll
-		for (int q = 0; q < kD10; q++) {
-			const long bo = b0 + 4 * q;
-			rp[q] = bo >= 0 ? *reinterpret_cast<const uint32_t *>(src + bo)
-					: *reinterpret_cast<const uint32_t *>(tail_in + (size_t)s * kTail10 + (kTail10 + bo));
-		}
-	}
+	__syncthreads();
+	// ---- the lane's outputs m0 + 8 tid + o: raw samples [10 m - 50, 10 m + 80) = logical dwords 40 tid + 3 + w, w < 65
+	const uint32_t *lp = raw + (kLaneDw10 + 1) * tid;  // physical dword of logical 40 tid
 	// (d*h) >> 10 per tap as one fp32 FMA in round-toward-minus-infinity mode, both rails per v_pk_fma_f32: see stage 1 of
-	// frontend_kernel.  The 60 taps' terms sum to less than 2^14.
+	// frontend_kernel.  The 60 taps' terms sum to less than 2^14.  The raw dwords come from LDS eight at a time, one group
+	// ahead of the one being consumed (all 65 up front cost 130 registers).
 	typedef float f32x2 __attribute__((ext_vector_type(2)));
 	const float kMagic = 12582912.0f;  // 2^23 + 2^22
 	f32x2 acc[kR10];
 #pragma unroll
 	for (int o = 0; o < kR10; o++)
 		acc[o] = f32x2{ kMagic, kMagic };
+	constexpr int kGrp = 8, kGroups10 = (kD10 + kGrp - 1) / kGrp;
+	uint32_t cur[kGrp], nxt[kGrp];
 #pragma unroll
-	for (int w = 0; w < kD10; w++) {  // one dword = two complex samples
-		const uint32_t v = rp[w] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
-		const f32x2 x[2] = { f32x2{ (float)(signed char)(v), (float)(signed char)(v >> 8) },
-				     f32x2{ (float)(signed char)(v >> 16), (float)((int)v >> 24) } };
+	for (int k = 0; k < kGrp; k++)
+		cur[k] = lp[pad10(3 + k)];
 #pragma unroll
-		for (int h = 0; h < 2; h++) {
-			const int c = 2 * w + h;  // sample index relative to 10 m - 50
+	for (int g = 0; g < kGroups10; g++) {
 #pragma unroll
-			for (int o = 0; o < kR10; o++) {
-				const int n = c - 10 * o;
-				if (n >= 0 && n < 60) {
-					const float hs = (float)kTaps10[n] * (1.0f / 1024.0f);
-					acc[o] = __builtin_elementwise_fma(x[h], f32x2{ hs, hs }, acc[o]);
+		for (int k = 0; k < kGrp; k++)
+			nxt[k] = kGrp * (g + 1) + k < kD10 ? lp[pad10(3 + kGrp * (g + 1) + k)] : 0u;
+#pragma unroll
+		for (int k = 0; k < kGrp; k++) {
+			const int w = kGrp * g + k;  // one dword = two complex samples
+			if (w < kD10) {
+				const uint32_t v = cur[k] ^ 0x80808080u;  // bytes become two's complement (u8 - 128)
+				const f32x2 x[2] = { f32x2{ (float)(signed char)(v), (float)(signed char)(v >> 8) },
+						     f32x2{ (float)(signed char)(v >> 16), (float)((int)v >> 24) } };
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const int c = 2 * w + h;  // sample index relative to 10 m - 50
+#pragma unroll
+					for (int o = 0; o < kR10; o++) {
+						const int n = c - 10 * o;
+						if (n >= 0 && n < 60) {
+							const float hs = (float)kTaps10[n] * (1.0f / 1024.0f);
+							acc[o] = __builtin_elementwise_fma(x[h], f32x2{ hs, hs }, acc[o]);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);  // (see above: a sample's FMAs stay together, accumulator by accumulator)
 				}
 			}
-			// the (up to six) FMAs of one sample go to different accumulators: none waits for the one before it.  Left to
-			// itself the scheduler chains the FMAs of an accumulator and pays a wait state for each
-			__builtin_amdgcn_sched_barrier(0);
 		}
+#pragma unroll
+		for (int k = 0; k < kGrp; k++)
+			cur[k] = nxt[k];
 	}
 	uint32_t ow[kR10];
 #pragma unroll
 	for (int o = 0; o < kR10; o++)  // the int16 store: the low half of the accumulator's mantissa
 		ow[o] = (__float_as_uint(acc[o].x) & 0xffffu) | (__float_as_uint(acc[o].y) << 16);
-	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)s * out_stride + m);
+	uint4 *dst = reinterpret_cast<uint4 *>(out + (size_t)s * out_stride + m0 + kR10 * tid);
 #pragma unroll
 	for (int q = 0; q < kR10 / 4; q++)
 		dst[q] = make_uint4(ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]);
@@ -445,7 +464,7 @@ hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int 
 {
 	const long n_out = (long)n_blocks * (TFREC_AMD_BLOCK_BYTES / 2);  // complex samples at 1.536 MS/s
 	dim3 grid((unsigned)((n_out + kT10 - 1) / kT10), n_streams);
-	hipLaunchKernelGGL(decim10_kernel, grid, dim3(256), 0, st, iq, stride, n_out, tail_in, tail_out, out, out_stride);
+	hipLaunchKernelGGL(decim10_kernel, grid, dim3(kThreads10), 0, st, iq, stride, n_out, tail_in, tail_out, out, out_stride);
 	return hipGetLastError();
 }
 
