@@ -87,55 +87,67 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTail + 16 * tid);
 
-	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes 4 consecutive outputs of both rails.
-	// Outputs k..k+3 need x[2k-6 .. 2k+7]: 28 raw bytes at offset base + 12 + 16*grp (k = 2*m0 - 22 + 4*grp).
-	// The tile needs 2*T + 24 of them: 2*T in two passes of the 256 lanes, the last 24 one per lane (below).
-	constexpr int kGroups = (2 * kTileDec) / 4;
-	static_assert(kGroups == 2 * kFrontThreads, "two full passes");
-#pragma unroll
-	for (int grp = tid; grp < kGroups; grp += kFrontThreads) {
-		uint32_t rp[7 * kB];
+	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes kG1 = 8 consecutive outputs of both rails (one pass of the
+	// 256 lanes makes the tile's 2*T; as two passes of four outputs each a lane converted 56 bytes instead of 44 and the
+	// loop's scalar work ran twice).  Outputs k..k+7 need x[2k-6 .. 2k+15]: 44 raw bytes at offset base + 12 + 32*grp
+	// (k = 2*m0 - 22 + 8*grp).  The tile needs 2*T + 24: the last 24 one per lane (below).
+	constexpr int kG1 = 8;
+	constexpr int kDw1 = (2 * kG1 + 6) * kB / 2;  // raw dwords per group: 11 (u8) / 22 (int16)
+	static_assert((2 * kTileDec) / kG1 == kFrontThreads, "one full pass");
+	typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(4)));
+	typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+	{
+		const int grp = tid;
+		uint32_t rp[kDw1];
 		{
-			const int off = kB * (12 + 16 * grp);  // from `base`
+			const int off = kB * (12 + 4 * kG1 * grp);  // from `base`
 			// every tile but the submit's first and last reads inside the stream: no bounds to check (a wave-uniform branch;
 			// the 64-bit compares of the checked path were a tenth of the kernel's vector instructions)
-			if (interior || (base + off >= 0 && base + off + 28 * kB <= nbytes)) {
+			if (interior || (base + off >= 0 && base + off + 4 * kDw1 <= nbytes)) {
 				const uint8_t *gp = src + base + off;
 				const u32x4_u *g = reinterpret_cast<const u32x4_u *>(gp);
 #pragma unroll
-				for (int q = 0; q < (7 * kB) / 4; q++) {
+				for (int q = 0; q < kDw1 / 4; q++) {
 					const u32x4_u v = g[q];
 					rp[4 * q] = v.x; rp[4 * q + 1] = v.y; rp[4 * q + 2] = v.z; rp[4 * q + 3] = v.w;
 				}
-#pragma unroll
-				for (int q = 4 * ((7 * kB) / 4); q < 7 * kB; q++)
-					rp[q] = reinterpret_cast<const uint32_t *>(gp)[q];
+				constexpr int kRest = kDw1 % 4, kDone = kDw1 - kRest;
+				if (kRest == 3) {
+					const u32x3_u v = *reinterpret_cast<const u32x3_u *>(gp + 4 * kDone);
+					rp[kDone] = v.x; rp[kDone + 1] = v.y; rp[kDone + 2] = v.z;
+				} else if (kRest == 2) {
+					const u32x2_u v = *reinterpret_cast<const u32x2_u *>(gp + 4 * kDone);
+					rp[kDone] = v.x; rp[kDone + 1] = v.y;
+				}
+				static_assert(kRest == 3 || kRest == 2, "11 or 22 dwords");
 			} else {
 #pragma unroll
-				for (int q = 0; q < 7 * kB; q++)
+				for (int q = 0; q < kDw1; q++)
 					rp[q] = raw_dword(base + off + 4 * q);
 			}
 		}
-		f32x2 oy[4];
+		f32x2 oy[kG1];
 		if (IN16) {
 			// int16 input: the same FMA form (below) with x * (h / 65536); x * h has up to 30 bits, which the FMA does not
 			// care about (it rounds once, after the exact product), the 8 terms sum to less than 2^16 in magnitude, and
 			// the int16 store of the reference (dsp_stuff.cpp:222) -- it can wrap here -- is the low half of the mantissa
-			f32x2 x[14];
+			f32x2 x[2 * kG1 + 6];
 #pragma unroll
-			for (int i = 0; i < 14; i++)
+			for (int i = 0; i < 2 * kG1 + 6; i++)
 				x[i] = f32x2{ (float)(int)(int16_t)(rp[i] & 0xffff), (float)((int)rp[i] >> 16) };
+			f32x2 acc[kG1];
 #pragma unroll
-			for (int o = 0; o < 4; o++) {
-				f32x2 acc = { kMagic, kMagic };
+			for (int n = 0; n < 8; n++) {
+				const float hs = (float)kS1[n] * (1.0f / 65536.0f);
 #pragma unroll
-				for (int n = 0; n < 8; n++) {
-					const float hs = (float)kS1[n] * (1.0f / 65536.0f);
-					acc = __builtin_elementwise_fma(x[2 * o + n], f32x2{ hs, hs }, acc);
-				}
-				oy[o] = f32x2{ (float)(int)(int16_t)(__float_as_uint(acc.x) & 0xffffu),
-					       (float)(int)(int16_t)(__float_as_uint(acc.y) & 0xffffu) };
+				for (int o = 0; o < kG1; o++)
+					acc[o] = __builtin_elementwise_fma(x[2 * o + n], f32x2{ hs, hs }, n == 0 ? f32x2{ kMagic, kMagic } : acc[o]);
+				__builtin_amdgcn_sched_barrier(0);  // (a tap's FMAs on different accumulators back to back: no wait states)
 			}
+#pragma unroll
+			for (int o = 0; o < kG1; o++)
+				oy[o] = f32x2{ (float)(int)(int16_t)(__float_as_uint(acc[o].x) & 0xffffu),
+					       (float)(int)(int16_t)(__float_as_uint(acc[o].y) & 0xffffu) };
 		} else {
 			// u8 input: d = u8 - 128 has 8 bits and h 14, so d * (h / 1024) is exact in fp32, and with the wave's fp32
 			// rounding mode set to "toward -inf" (top of the kernel)
@@ -144,26 +156,29 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			// ONE instruction per tap -- and v_pk_fma_f32 does the I and the Q rail at once.  (The integer form costs a
 			// multiply and an add per tap and rail.)  The 8 taps sum to at most 8 * 1782, so acc stays in range and the
 			// int16 store of the reference (dsp_stuff.cpp:222) changes nothing.
-			f32x2 d[14];
+			f32x2 d[2 * kG1 + 6];
 #pragma unroll
-			for (int i = 0; i < 7; i++) {
+			for (int i = 0; i < kDw1; i++) {
 				const uint32_t w = rp[i] ^ 0x80808080u;  // bytes become two's complement: one signed byte conversion each
 				d[2 * i] = f32x2{ (float)(signed char)(w), (float)(signed char)(w >> 8) };
 				d[2 * i + 1] = f32x2{ (float)(signed char)(w >> 16), (float)((int)w >> 24) };
 			}
+			f32x2 acc[kG1];
 #pragma unroll
-			for (int o = 0; o < 4; o++) {
-				f32x2 acc = { kMagic, kMagic };  // 2^23 + 2^22: room for negative sums
+			for (int n = 0; n < 8; n++) {
+				const float hs = (float)kS1[n] * (1.0f / 1024.0f);
 #pragma unroll
-				for (int n = 0; n < 8; n++) {
-					const float hs = (float)kS1[n] * (1.0f / 1024.0f);
-					acc = __builtin_elementwise_fma(d[2 * o + n], f32x2{ hs, hs }, acc);
-				}
-				oy[o] = acc - f32x2{ kMagic, kMagic };  // exact
+				for (int o = 0; o < kG1; o++)  // (2^23 + 2^22: room for negative sums)
+					acc[o] = __builtin_elementwise_fma(d[2 * o + n], f32x2{ hs, hs }, n == 0 ? f32x2{ kMagic, kMagic } : acc[o]);
+				__builtin_amdgcn_sched_barrier(0);  // (a tap's FMAs on different accumulators back to back: no wait states)
 			}
+#pragma unroll
+			for (int o = 0; o < kG1; o++)
+				oy[o] = acc[o] - f32x2{ kMagic, kMagic };  // exact
 		}
-		*reinterpret_cast<f32x4 *>(&y1[4 * grp]) = f32x4{ oy[0].x, oy[0].y, oy[1].x, oy[1].y };
-		*reinterpret_cast<f32x4 *>(&y1[4 * grp + 2]) = f32x4{ oy[2].x, oy[2].y, oy[3].x, oy[3].y };
+#pragma unroll
+		for (int q = 0; q < kG1 / 2; q++)
+			*reinterpret_cast<f32x4 *>(&y1[kG1 * grp + 2 * q]) = f32x4{ oy[2 * q].x, oy[2 * q].y, oy[2 * q + 1].x, oy[2 * q + 1].y };
 	}
 	// ---- ... and the 24 stage-1 outputs behind them (slots 2*T .. 2*T + 23: the far end of the tile's last stage-2
 	// windows), ONE per lane of the first 24: 8 samples = 16 raw bytes (x kB) at offset 4*slot + 12.  As a third pass of the
