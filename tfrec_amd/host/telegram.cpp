@@ -481,15 +481,10 @@ void whb_decoder::payload(uint32_t stype, const uint8_t *m, uint64_t id, int rss
 	}
 	case 0x0b: {  // wind: 24-bit sequence, values kept in single precision like the reference
 		const int seq24 = (m[0] << 16) | (m[1] << 8) | m[2];
-		float dir = 0, speed = 0, gust = 0;  // the newest of six history entries is the reading; -D prints them all
-		for (int i = 5; i >= 0; i--) {
-			const uint8_t *e = m + 3 + 4 * i;
-			const uint32_t v = ((uint32_t)e[0] << 24) | (e[1] << 16) | (e[2] << 8) | e[3];
-			dir = 22.5 * (v >> 28);
-			speed = (((v >> 16) & 0xff) + 256 * ((v >> 25) & 1)) / 10.0;
-			gust = (((v >> 8) & 0xff) + 256 * ((v >> 24) & 1)) / 10.0;
-			(void)0;
-		}
+		// the newest of six history entries (entry 0) is the reading; -D prints them all
+		const uint32_t v0 = ((uint32_t)m[3] << 24) | (m[4] << 16) | (m[5] << 8) | m[6];
+		const float dir = 22.5 * (v0 >> 28), speed = (((v0 >> 16) & 0xff) + 256 * ((v0 >> 25) & 1)) / 10.0,
+			    gust = (((v0 >> 8) & 0xff) + 256 * ((v0 >> 24) & 1)) / 10.0;
 		for (int i = 0; i < 6 && show && (i == 0 || dbg > 0); i++) {
 			const uint8_t *e = m + 3 + 4 * i;
 			const uint32_t v = ((uint32_t)e[0] << 24) | (e[1] << 16) | (e[2] << 8) | e[3];
