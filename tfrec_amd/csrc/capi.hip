@@ -731,9 +731,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		// checks of consecutive submits and waits for ALL chains of its submit: the check of submit k + 1 could not start
 		// before the TFA chains of submit k had ended.  6.32 -> 6.21 ms per batch over 100 steps
 		// (profiles/r04_ab_copy_stream.txt); the low pool's hardware queues hold only this stream and the discriminator's.
-		if (c->deep && rc == TFREC_AMD_OK && !(getenv("TFREC_AMD_COPY_OWN") && atoi(getenv("TFREC_AMD_COPY_OWN")) == 0) &&
-		    hipStreamCreateWithPriority(&c->cq, hipStreamNonBlocking, prio_lo) != hipSuccess)
-			rc = TFREC_AMD_E_HIP;
+		{  // (TFREC_AMD_COPY_OWN: 0 = on cp, 1 = low priority (default), 2 = normal, 3 = high)
+			const int m = getenv("TFREC_AMD_COPY_OWN") ? atoi(getenv("TFREC_AMD_COPY_OWN")) : 1;
+			if (c->deep && rc == TFREC_AMD_OK && m > 0 &&
+			    hipStreamCreateWithPriority(&c->cq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+		}
 		// whb_verify_kernel runs on the copy stream, ahead of its submit's device-to-host copies (they wait for it anyway).
 		// A stream of its own would be the FIFTH of normal priority in the process (k2, kw, cp and the caller's): it shared a
 		// hardware queue with kw, and the 6 ms verification of submit k held up the WHB biquads of submit k + 2.
