@@ -20,9 +20,18 @@ Rank 0 prints ONE JSON line with the contract fields plus
                   never `value`),
   "ms_min/ms_median/ms_max": per-step dispersion (time between consecutive drains inside the timed region);
   "ms_per_step_steady": the same without the steps in which the FIFO fills and drains.
-Parity gate (before the timed region, on fresh state): EVERY stream of the batch at N=1 (128 spread over the batch per
-rank at N>1) against the CPU oracle; after the timed region the discriminator's self-check counters
-(config.atan_*: samples decided by the exact slow path / differing from this host's libm) -- a mismatch fails the run.
+  "roofline" also states what binds: hbm_floor_ms (2 B per input sample at 8 TB/s), algorithmic_valu_floor_ms (the reference's
+                  arithmetic 64 lanes wide at one instruction per SIMD and quad-cycle: derivation above ALG_OPS and in
+                  DESIGN.md 3), chain_floor_ms (the longest kernel alone on the chip: the serial WHB chains),
+                  period_over_max_floor, frontend = {ms_alone, frac}; valu_profiled.* and traffic* come from the builder's
+                  committed rocprofv3 runs of this command (profiles/, named in the block), not from this run.
+  "roofline.kernel" is the kernel with the longest live HIP-event span inside the overlapped pipeline (it includes the
+                  kernel's waits for issue slots beside the other streams' kernels).
+Parity gates: BEFORE the timed region, on fresh state, EVERY stream of the batch at N=1 (128 spread over the batch per
+rank at N>1) against the CPU oracle; AFTER it one more batch through the same context (carried decoder / biquad / slicer
+state, FIFO four deep) with 64 streams against the oracle continued over every repetition of the input the context has
+seen (config.parity_after_timed*); and the discriminator's self-check counters (config.atan_*: samples decided by the
+exact slow path / differing from this host's libm).  A mismatch in any of them fails the run.
 """
 from __future__ import annotations
 
