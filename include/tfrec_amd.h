@@ -218,8 +218,9 @@ typedef struct {
 	uint64_t reserved[1];
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
-/* Number of internal HIP streams the context's pipeline is laid out on: 6 = deep (default: the filter stage of submit
- * k+1 runs beside the slicer/decoder stage of submit k), 4 = shallow (environment TFREC_AMD_DEEP=0 when the context is
+/* Layout of the context's pipeline, named by its number of CHAIN streams: 6 = deep (default: the filter stage of submit
+ * k+1 runs beside the slicer/decoder stage of submit k; plus the front-end stream and two low-priority streams for the
+ * discriminator pass and the drain's copy), 4 = shallow (environment TFREC_AMD_DEEP=0 when the context is
  * created), 2 = the serial cross-check (TFREC_AMD_F_SERIAL_CHAINS).  Results do not depend on it.  No reference
  * counterpart. */
 int tfrec_amd_get_layout(tfrec_amd_ctx *ctx, int *n_streams);
