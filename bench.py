@@ -298,8 +298,8 @@ def main():
             for u in src.tolist():
                 o = O.Oracle(a.types, a.thresh, 0)
                 o.process_s16(O.decim10(host[u]))
-                orc[u] = np.array([(e[0][0], e[0][2], e[0][3], e[0][4], e[0][1], e[1], np.frombuffer(e[0][5], np.uint8))
-                                   for e in o.events_raw()], dtype=O.ORC_EVENT_DTYPE)
+                orc[u] = np.array([(e[0], e[7], e[2], e[3], e[4], e[1], e[6], np.frombuffer(e[5], np.uint8))
+                                   for e in o.events_full()], dtype=O.ORC_EVENT_DTYPE)
         minb = np.array([10, 7, 7, 7, 11])
         gs, gm = api.events_canon(first)
         bounds = np.searchsorted(gs, np.arange(n_streams + 1))  # the drain orders by (stream, slot, seq)
@@ -455,9 +455,9 @@ def main():
                         o.process_s16(O.decim10(xh[k]))
                     else:
                         o.process(xh[k])
-                    want = sorted(e for e in o.events() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
+                    want = sorted(e for e in o.events_full() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
                                   and not (e[0] == 4 and e[2] > 60))
-                    ok = ok and sorted(api.event_tuples(first, k)) == want
+                    ok = ok and sorted(api.event_tuples_full(first, k)) == want
                 q = 0
                 for k in range(3):  # warm-up
                     xr_.submit(xd)

@@ -22,7 +22,8 @@ SLOT_NAMES = ("TFA_1", "TFA_2", "TFA_3", "TX22", "WHB")
 
 class Event(C.Structure):
     _fields_ = [
-        ("slot", C.c_int32),
+        ("slot", C.c_int16),
+        ("status", C.c_int16),
         ("byte_cnt", C.c_int32),
         ("rssi_db", C.c_int32),
         ("offset", C.c_int32),
@@ -175,6 +176,13 @@ class Oracle:
         p = self.L.orc_events(self.h)
         return [(event_tuple(p[i]), int(p[i].rssi_raw)) for i in range(n)]
 
+    def events_full(self):
+        """event_tuple + the raw RSSI accumulator (tfa1.cpp:161, tfa2.cpp:373, whb.cpp:678) + what flush() made of the
+        bytes (0 too short, 1 telegram, 2 rejected by CRC / sanity: tfa1.cpp:63-73, tfa2.cpp:93/237, whb.cpp:506-510)."""
+        n = self.L.orc_num_events(self.h)
+        p = self.L.orc_events(self.h)
+        return [event_tuple(p[i]) + (int(p[i].rssi_raw), int(p[i].status)) for i in range(n)]
+
     def data(self):
         n = self.L.orc_num_data(self.h)
         p = self.L.orc_data(self.h)
@@ -197,7 +205,7 @@ class Oracle:
         self.L.orc_clear_logs(self.h)
 
 
-ORC_EVENT_DTYPE = np.dtype([("slot", "<i4"), ("byte_cnt", "<i4"), ("rssi_db", "<i4"), ("offset", "<i4"),
+ORC_EVENT_DTYPE = np.dtype([("slot", "<i2"), ("status", "<i2"), ("byte_cnt", "<i4"), ("rssi_db", "<i4"), ("offset", "<i4"),
                             ("end_sample", "<i8"), ("rssi_raw", "<i8"), ("rdata", "u1", (64,))])
 assert ORC_EVENT_DTYPE.itemsize == 96
 
@@ -253,11 +261,14 @@ def process_parts(parts, types_mask: int = 0x2F, thresh: int = 500, wide: int = 
 
 
 def canon(ev: np.ndarray) -> np.ndarray:
-    """Comparable matrix [n, 5 + 64] of ORC_EVENT_DTYPE events: slot, end_sample, byte_cnt, rssi_db, offset, rdata."""
-    m = np.empty((len(ev), 69), dtype=np.int64)
+    """Comparable matrix [n, 5 + 64 + 2] of ORC_EVENT_DTYPE events: slot, end_sample, byte_cnt, rssi_db, offset, rdata,
+    rssi_raw, status."""
+    m = np.empty((len(ev), 71), dtype=np.int64)
     for k, f in enumerate(("slot", "end_sample", "byte_cnt", "rssi_db", "offset")):
         m[:, k] = ev[f]
-    m[:, 5:] = ev["rdata"]
+    m[:, 5:69] = ev["rdata"]
+    m[:, 69] = ev["rssi_raw"]
+    m[:, 70] = ev["status"]
     return m
 
 

@@ -474,10 +474,12 @@ static void emit_data(orc_t *o, dec_t *d, int type, uint64_t id, double temp, do
 	} while (0)
 
 /* tfa1.cpp:47-118 */
-static void tfa1_flush(orc_t *o, dec_t *d, int rssi)
+static int tfa1_flush(orc_t *o, dec_t *d, int rssi)
 {
 	uint8_t *r = d->rdata;
+	int verdict = 0;
 	if (d->byte_cnt >= 10) {
+		verdict = 2;
 		int id = ((r[2] << 8) | r[3]) & 0x7fff;
 		int batfail = (r[7] & 0x80) >> 7;
 		double temp = ((r[4] & 0xf) * 100) + ((r[5] >> 4) * 10) + (r[5] & 0xf);
@@ -495,6 +497,7 @@ static void tfa1_flush(orc_t *o, dec_t *d, int rssi)
 				hum = 0;
 				temp = 0;
 			}
+			verdict = 1;
 			TXT(o, "TFA1 ID %04x %+.1f %i%% seq %x lowbat %i RSSI %i\n", id, temp, hum, seq, batfail, rssi);
 			emit_data(o, d, T_TFA_1, (uint64_t)id, temp, hum, seq, batfail, rssi);
 		}
@@ -502,13 +505,16 @@ static void tfa1_flush(orc_t *o, dec_t *d, int rssi)
 	d->sr_cnt = -1;
 	d->byte_cnt = 0;
 	r[10] = 0x00;
+	return verdict;
 }
 
 /* tfa2.cpp:219-279 */
-static void tfa2_flush_tfa(orc_t *o, dec_t *d, int rssi, int offset)
+static int tfa2_flush_tfa(orc_t *o, dec_t *d, int rssi, int offset)
 {
 	uint8_t *r = d->rdata;
+	int verdict = 0;
 	if (d->byte_cnt >= 7) {
+		verdict = 2;
 		int id = (d->type << 28) | (r[2] << 8) | (r[3] & 0xc0);
 		double temp = ((r[3] & 0xf) * 100 + (r[4] >> 4) * 10 + (r[4] & 0xf));
 		temp = temp * 0.1 - 40;
@@ -518,6 +524,7 @@ static void tfa2_flush_tfa(orc_t *o, dec_t *d, int rssi, int offset)
 		if (hum == 0x7d)
 			id |= 1;
 		if (crc_val == crc_calc) {
+			verdict = 1;
 			if (hum > 100)
 				hum = 0;
 			TXT(o, "TFA%i ID %06x %+.1lf %i%% RSSI %i Offset %.0lfkHz\n", d->type + 1, id, temp, hum, rssi,
@@ -528,12 +535,14 @@ static void tfa2_flush_tfa(orc_t *o, dec_t *d, int rssi, int offset)
 	d->sr_cnt = -1;
 	d->sr = 0;
 	d->byte_cnt = 0;
+	return verdict;
 }
 
 /* tfa2.cpp:72-217 */
-static void tfa2_flush_tx22(orc_t *o, dec_t *d, int rssi, int offset)
+static int tfa2_flush_tx22(orc_t *o, dec_t *d, int rssi, int offset)
 {
 	uint8_t *r = d->rdata;
+	int verdict = (d->byte_cnt >= 7 && d->byte_cnt < 64) ? 2 : 0;
 	if (d->byte_cnt >= 7 && d->byte_cnt < 64 && (r[2] >> 4) == 0xa) {
 		int id = ((r[2] & 0xf) << 2) | (r[3] >> 6);
 		int error = !((r[3] >> 4) & 1);
@@ -542,6 +551,7 @@ static void tfa2_flush_tx22(orc_t *o, dec_t *d, int rssi, int offset)
 		uint8_t crc_val = r[2 * num + 4];
 		uint8_t crc_calc = orc_crc8(&r[2], 2 + 2 * num);
 		if (crc_val == crc_calc && num <= 8) {
+			verdict = 1;
 			int have_temp = 0, have_hum = 0, have_rain = 0, have_wind = 0, have_gust = 0;
 			double temp = 0, hum = 0, rain = 0, wdir = 0, wspeed = 0, wgust = 0;
 			for (int n = 0; n < num; n++) {
@@ -601,6 +611,7 @@ static void tfa2_flush_tx22(orc_t *o, dec_t *d, int rssi, int offset)
 	d->sr_cnt = -1;
 	d->sr = 0;
 	d->byte_cnt = 0;
+	return verdict;
 }
 
 /* ---- WHB payload parsers (whb.cpp:109-475) */
@@ -754,10 +765,12 @@ static void whb_payload(orc_t *o, dec_t *d, uint32_t stype, const uint8_t *msg, 
 }
 
 /* whb.cpp:477-564 */
-static void whb_flush(orc_t *o, dec_t *d, int rssi)
+static int whb_flush(orc_t *o, dec_t *d, int rssi)
 {
 	uint8_t *r = d->rdata;
+	int verdict = 0;
 	if (!(d->byte_cnt < 11 || d->byte_cnt > 60)) {
+		verdict = 2;
 		int plen = r[4];
 		if (plen <= 60) {
 			uint32_t stype = r[5], init;
@@ -768,6 +781,7 @@ static void whb_flush(orc_t *o, dec_t *d, int rssi)
 				uint32_t crc_calc = orc_crc32(&r[4], plen - 4, init);
 				uint32_t crc_val = BE32(&r[plen]);
 				if (crc_calc == crc_val) {
+					verdict = 1;
 					uint64_t id = 0;
 					for (int n = 0; n < 6; n++)
 						id = (id << 8) | r[5 + n];
@@ -780,6 +794,7 @@ static void whb_flush(orc_t *o, dec_t *d, int rssi)
 	d->sr = 0;
 	d->byte_cnt = 0;
 	d->synced = 0;
+	return verdict;
 }
 
 static void dem_store_bit(orc_t *o, dem_t *m, int bit)
@@ -794,16 +809,20 @@ static void dem_store_bit(orc_t *o, dem_t *m, int bit)
 
 static void dem_flush(orc_t *o, dem_t *m, int rssi_db, int offset, int64_t rssi_raw)
 {
+	const size_t nev0 = o->nev;
+	int verdict;
 	log_event(o, &m->dec, rssi_db, offset, rssi_raw);
 	if (m->kind == 0)
-		tfa1_flush(o, &m->dec, rssi_db);
+		verdict = tfa1_flush(o, &m->dec, rssi_db);
 	else if (m->kind == 1) {
 		if (m->dec.type == T_TX22)
-			tfa2_flush_tx22(o, &m->dec, rssi_db, offset);
+			verdict = tfa2_flush_tx22(o, &m->dec, rssi_db, offset);
 		else
-			tfa2_flush_tfa(o, &m->dec, rssi_db, offset);
+			verdict = tfa2_flush_tfa(o, &m->dec, rssi_db, offset);
 	} else
-		whb_flush(o, &m->dec, rssi_db);
+		verdict = whb_flush(o, &m->dec, rssi_db);
+	if (o->nev > nev0) /* what flush() made of the bytes the event holds */
+		o->ev[o->nev - 1].status = (int16_t)verdict;
 }
 
 /* ---------------------------------------------------------------- demod steps */

@@ -14,7 +14,10 @@ extern "C" {
 #define ORC_BLOCK_DEC 8192 /* decimated IQ pairs per block */
 
 typedef struct {
-	int32_t slot;       /* 0..4 */
+	int16_t slot;       /* 0..4 */
+	int16_t status;     /* what the decoder's flush() did with it: 0 = shorter than a telegram (tfa1.cpp:49, tfa2.cpp:76/222,
+			       whb.cpp:484), 1 = passed its CRC + sanity tests (tfa1.cpp:63-73, tfa2.cpp:93/237, whb.cpp:506-510),
+			       2 = rejected by them */
 	int32_t byte_cnt;   /* decoder byte_cnt when flush() was entered */
 	int32_t rssi_db;    /* first flush() argument as the demodulator computed it */
 	int32_t offset;     /* second flush() argument */

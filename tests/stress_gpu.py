@@ -53,8 +53,8 @@ def _round(rng, rnd, verbose):
             for s in range(n_streams):
                 o = O.Oracle(types, thresh, wide)
                 o.process(iq[s])
-                want = sorted(o.events())
-                got = sorted(api.event_tuples(ev, s))
+                want = sorted(o.events_full())
+                got = sorted(api.event_tuples_full(ev, s))
                 if got != want:
                     ok = False
             unc = r.atan_uncertain()

@@ -28,8 +28,10 @@ def by_slot(evs):
 
 
 def check_stream(gpu_events, stream, orc, min_bytes_only=False):
-    g = by_slot(api.event_tuples(gpu_events, stream))
-    oe = orc.events()
+    # full tuples: ..., rssi_raw (the accumulator itself, not only its dB value: BASELINE.md 3 "raw RSSI and offset integers
+    # identical"), status (the decoder's CRC / sanity verdict of every event, computed on the GPU)
+    g = by_slot(api.event_tuples_full(gpu_events, stream))
+    oe = orc.events_full()
     if min_bytes_only:
         minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
         oe = [e for e in oe if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64) and not (e[0] == 4 and e[2] > 60)]
@@ -86,6 +88,29 @@ def test_default_mode_reports_candidates_with_verdict():
             n_ok = int(np.sum((ev["stream"] == s) & (ev["status"] == 1)))
             lines = [ln for ln in orc.text().splitlines() if not ln.startswith("Inverted") and not ln.startswith("WHB:")]
             assert n_ok == len(lines)
+
+
+@SERIAL
+@pytest.mark.parametrize("all_flushes", [True, False], ids=["all_flushes", "default"])
+def test_planted_crc_and_sanity_failures_status_per_event(serial, all_flushes):
+    """Every other burst carries a planted fault (synth.gen_stream corrupt_every: wrong checksum / right checksum but a field
+    the decoder's sanity test rejects / frame cut short, in turn): the verdict the GPU computes for EVERY event (status:
+    tfa1.cpp:63-73, tfa2.cpp:93/237, whb.cpp:506-510 + the length tests) equals the oracle's, event by event, and so do the
+    raw RSSI accumulators."""
+    n_streams, n_blocks = 10, 48
+    iq = np.stack([synth.gen_stream(31, s, n_blocks, corrupt_every=2) for s in range(n_streams)])
+    seen = {0: 0, 1: 0, 2: 0}
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=all_flushes, serial_chains=serial) as r:
+        r.submit(iq)
+        ev = r.drain()
+        for s in range(n_streams):
+            check_stream(ev, s, oracle_events(iq[s], 0x2F, 500), min_bytes_only=not all_flushes)
+        for st in seen:
+            seen[st] = int(np.sum(ev["status"] == st))
+    # planted: rejected telegrams of every protocol next to accepted ones
+    rej = ev[ev["status"] == 2]
+    assert seen[1] >= 5 * n_streams and seen[2] >= 5 * n_streams and sorted(set(rej["slot"].tolist())) == [0, 1, 2, 3, 4]
+    assert (seen[0] > 0) == all_flushes
 
 
 @SERIAL

@@ -24,6 +24,20 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def _status_pinned_by_text(o, ref_lines):
+    """The per-event verdict the oracle exports (orc_event_t.status) against the REAL reference's output: every flush its
+    decoder accepts prints exactly one telegram line (tfa1.cpp:89, tfa2.cpp:169/249, whb.cpp:126-475), per protocol; a
+    flush shorter than a telegram is 0, everything else 2."""
+    full = o.events_full()
+    minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
+    for slot, prefix in ((0, "TFA1 "), (1, "TFA2 "), (2, "TFA3 "), (3, "TX22 "), (4, "WHB")):
+        lines = [ln for ln in ref_lines if ln.startswith(prefix) and not ln.startswith("WHB:")]
+        assert sum(1 for e in full if e[0] == slot and e[7] == 1) == len(lines), prefix
+    for e in full:
+        too_short = e[2] < minb[e[0]] or (e[0] == 3 and e[2] >= 64) or (e[0] == 4 and e[2] > 60)
+        assert (e[7] == 0) == too_short
+
+
 def test_readme_known_answer(golden_dir):
     # README.md:123 of the reference: the only in-tree known answer
     o = O.Oracle(0x01)
@@ -40,6 +54,7 @@ def test_byte_level_known_answers(golden_dir):
         assert [ln for ln in o.text().splitlines() if ln.strip()] == c["text"], c["hex"]
         assert o.data() == _data(c["data"]), c["hex"]
         assert o.events() == _events(c["events"]), c["hex"]
+        _status_pinned_by_text(o, c["text"])
 
 
 def test_unit_probes(golden_dir):
@@ -70,6 +85,7 @@ def test_synthetic_streams_against_reference_outputs(golden_dir):
         assert o.events() == _events(c["events"])
         assert o.data() == _data(c["data"])
         assert o.text() == c["text"]
+        _status_pinned_by_text(o, c["text"].splitlines())
 
 
 def _inverted_iq(c):

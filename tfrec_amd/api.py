@@ -304,11 +304,11 @@ def fm_dev_probe(records: np.ndarray, device: int = 0, cross: bool = False):
 
 
 def events_canon(events: np.ndarray):
-    """Vector form of event_tuples for whole batches: (stream[n], int64 matrix [n, 5 + 64] with the columns slot,
-    end_sample, byte_cnt, rssi_db, offset, rdata) -- the layout of oracle.canon()."""
+    """Vector form of event_tuples_full for whole batches: (stream[n], int64 matrix [n, 5 + 64 + 2] with the columns slot,
+    end_sample, byte_cnt, rssi_db, offset, rdata, rssi_raw, status) -- the layout of oracle.canon()."""
     L = load_library()
     events = events[events["status"] != STATUS_BITS]
-    m = np.empty((len(events), 69), dtype=np.int64)
+    m = np.empty((len(events), 71), dtype=np.int64)
     m[:, 0] = events["slot"]
     m[:, 1] = events["end_sample"]
     m[:, 2] = events["byte_cnt"]
@@ -316,7 +316,9 @@ def events_canon(events: np.ndarray):
     raws = events["rssi_raw"].tolist()
     m[:, 3] = [L.tfrec_amd_rssi_db(sl, rw) for sl, rw in zip(slots, raws)]
     m[:, 4] = events["offset"]
-    m[:, 5:] = events["rdata"]
+    m[:, 5:69] = events["rdata"]
+    m[:, 69] = events["rssi_raw"]
+    m[:, 70] = events["status"]
     return events["stream"].astype(np.int64), m
 
 
@@ -331,6 +333,20 @@ def bits_by_flush(events: np.ndarray, stream: int):
         bits = np.unpackbits(e["rdata"], bitorder="little")[:n]
         key = (int(e["slot"]), int(e["seq"]))
         out[key] = out.get(key, "") + "".join("01"[b] for b in bits)
+    return out
+
+
+def event_tuples_full(events: np.ndarray, stream: int | None = None):
+    """event_tuples + (rssi_raw, status): the raw RSSI accumulator itself (tfa1.cpp:161, tfa2.cpp:373, whb.cpp:678) and the
+    verdict of the decoder's acceptance tests computed on the GPU -- what oracle.Oracle.events_full() returns."""
+    L = load_library()
+    out = []
+    for e in events:
+        if (stream is not None and int(e["stream"]) != stream) or int(e["status"]) == STATUS_BITS:
+            continue
+        out.append((int(e["slot"]), int(e["end_sample"]), int(e["byte_cnt"]),
+                    int(L.tfrec_amd_rssi_db(int(e["slot"]), int(e["rssi_raw"]))), int(e["offset"]),
+                    bytes(e["rdata"]), int(e["rssi_raw"]), int(e["status"])))
     return out
 
 

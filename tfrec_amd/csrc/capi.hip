@@ -37,8 +37,11 @@ using namespace tfrec;
 // Buffer / table sets = submits that may be in flight (the FIFO depth): front end of submit k+2, biquad stage of
 // k+1 and slicer stage of k run beside each other in the deep layout
 constexpr int kSets = TFREC_AMD_FIFO_DEPTH;
-// header of a set's event block: EventBuf + 16 bytes (the window tables' overflow flag), padded
-constexpr size_t kEvHeader = (sizeof(EventBuf) + 16 + 255) & ~(size_t)255;
+// header of a set's event block: EventBuf + 16 bytes (the window tables' overflow flag, at kEvOverflowOff on the device and
+// in the host copy alike), padded
+constexpr size_t kEvOverflowOff = sizeof(EventBuf);
+constexpr size_t kEvFreshBytes = kEvOverflowOff + 16;  // what a submit resets from d_eb_fresh: EventBuf + the flag
+constexpr size_t kEvHeader = (kEvFreshBytes + 255) & ~(size_t)255;
 
 static thread_local char g_err[256] = "";
 
@@ -510,12 +513,17 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			ALLOC(c->d_whbgen, n * sizeof(uint32_t));
 			ALLOC(c->d_whbX, n * sizeof(ChainState));
 			ALLOC(c->d_whbscr, n * sizeof(ChainState));
+			// TEST hooks (results stay exact under both: the check's tolerance and the ambiguity rule widen with D, and a forced
+			// failure is only a redo) -- clamped, and never silent: a stray variable changes the redo rate, i.e. the speed
 			if (const char *tp = getenv("TFREC_AMD_WHB_TEST_PERTURB"))
-				c->whb_test_perturb = atoi(tp);
+				c->whb_test_perturb = std::max(-1000000, std::min(1000000, atoi(tp)));
 			if (rc == TFREC_AMD_OK && hipMemset(c->d_whbgen, 0, n * sizeof(uint32_t)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 			if (const char *ff = getenv("TFREC_AMD_WHB_FORCE_FAIL"))
-				c->whb_force_fail = atoi(ff);
+				c->whb_force_fail = std::max(0, atoi(ff));
+			if (c->whb_test_perturb || c->whb_force_fail)
+				fprintf(stderr, "tfrec_amd: TEST hook active (TFREC_AMD_WHB_TEST_PERTURB=%d, TFREC_AMD_WHB_FORCE_FAIL=%d): WHB streams are "
+						"redone on purpose, results unchanged, throughput lower\n", c->whb_test_perturb, c->whb_force_fail);
 			if (rc == TFREC_AMD_OK && (hipMemset(c->d_whbx, 0, n * sizeof(WhbExact)) != hipSuccess ||
 						   hipMemset(c->d_whbcarry, 0, n * sizeof(int)) != hipSuccess))
 				rc = TFREC_AMD_E_HIP;
@@ -524,6 +532,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		WinTables &T = c->win[set];
 		T.cap = (int32_t)(m_max / 356 + 2);  // windows of one chain are > W-1 >= 355 samples apart
 		T.slots = (int32_t)(m_max / 32 + (size_t)T.cap + 2);  // window-relative 32-sample slots per chain row
+		if ((size_t)T.slots > (size_t)kWhbRecOffMask) {  // WhbStepRec::meta packs a slot index into kWhbRecOffMask's bits
+			snprintf(g_err, sizeof(g_err), "max_blocks too large for the WHB step records");
+			rc = TFREC_AMD_E_INVAL;
+			break;
+		}
 		// rows only for the chains that use them: ld16 for the TFA_2 family (its slots are adjacent in registration order),
 		// checkpoints for the chains with a biquad stage (all but TFA_1, which is registered first)
 		int a_ld0 = -1, n_ld = 0, a_ck0 = -1;
@@ -554,7 +567,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_open = carve(wins * 4), o_close = carve(wins * 4), o_res = carve(wins * sizeof(WinResult));
 		const size_t o_dcd = carve(wins * sizeof(WinDecode)), o_wst = carve(whb ? n * (size_t)T.cap * sizeof(WhbStart) : 0);
 		const size_t o_bits = carve(chains * (size_t)T.bit_words * 4), o_items = carve((kNQueues * wins + chains) * sizeof(uint2));
-		const size_t o_queue = carve((kNQueues + 1) * sizeof(WorkQueue)), o_ovf = carve(4), o_stats = carve(128);
+		const size_t o_queue = carve((kNQueues + 1) * sizeof(WorkQueue)), o_stats = carve(128);
 		T.segcap = (int32_t)((m_max / 32 + (size_t)T.cap) / kSegSlots + 2);
 		const size_t segs = chains * (size_t)T.segcap;
 		const size_t o_ckpt = carve(ck_chains * (size_t)T.slots * sizeof(double2));
@@ -580,7 +593,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.bits = (uint32_t *)(b + o_bits);
 			T.items = (uint2 *)(b + o_items);
 			T.queue = (WorkQueue *)(b + o_queue);
-			T.overflow = (int32_t *)(b + o_ovf);
+			T.overflow = nullptr;  // lives in the set's event block (kEvOverflowOff): set below, reset by every submit
 			T.stats = (unsigned long long *)(b + o_stats);
 			T.ckpt = (double2 *)(b + o_ckpt);
 			T.segstart = (uint2 *)(b + o_sstart);
@@ -606,7 +619,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.whbx = c->d_whbx;
 			T.timeout_carry = c->d_tcarry;
 			T.prevdec = c->d_prevdec[set];
-			if (hipMemset(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue)) != hipSuccess || hipMemset(T.overflow, 0, 4) != hipSuccess ||
+			if (hipMemset(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue)) != hipSuccess ||
 			    hipMemset(T.stats, 0, 128) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
@@ -631,10 +644,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			c->d_eb[k] = (EventBuf *)c->d_evblock[k];
 			c->d_events[k] = (tfrec_amd_event *)(c->d_evblock[k] + kEvHeader);
 			if (c->win[k].count)  // (window-parallel pipeline: its overflow flag lives behind the EventBuf)
-				c->win[k].overflow = (int32_t *)(c->d_evblock[k] + sizeof(EventBuf));
+				c->win[k].overflow = (int32_t *)(c->d_evblock[k] + kEvOverflowOff);
 		}
 	}
-	ALLOC(c->d_eb_fresh, sizeof(EventBuf) + 16);
+	ALLOC(c->d_eb_fresh, kEvFreshBytes);
 #undef ALLOC
 	for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++) {
 		if (hipHostMalloc((void **)&c->h_evblock[k], kEvHeader + (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
@@ -670,7 +683,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		    hipMemset(c->d_tail[1], c->in10x ? 0 : 0x80, n * tail_bytes) != hipSuccess ||
 		    (c->in10x && (hipMemset(c->d_tail10[0], 0x80, n * 112) != hipSuccess ||
 				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
-		    hipMemset(c->d_eb_fresh, 0, sizeof(EventBuf) + 16) != hipSuccess ||
+		    hipMemset(c->d_eb_fresh, 0, kEvFreshBytes) != hipSuccess ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
 		    mkstream(&c->fs, 0, prio_fs) != hipSuccess ||
 		    mkstream(&c->cp, 1, 0) != hipSuccess ||
@@ -798,7 +811,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		HIPCHK(hipEventRecord(c->ev_in[set], (hipStream_t)hip_stream));
 		HIPCHK(hipStreamWaitEvent(fs, c->ev_in[set], 0));
 	}
-	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, sizeof(EventBuf) + 16, hipMemcpyDeviceToDevice, fs));  // (+ the overflow flag)
+	HIPCHK(hipMemcpyAsync(c->d_eb[set], c->d_eb_fresh, kEvFreshBytes, hipMemcpyDeviceToDevice, fs));  // (+ the overflow flag)
 	if (timing)
 		HIPCHK(hipEventRecord(c->ev[set][0], fs));
 	const uint8_t *fin = (const uint8_t *)d_iq;
@@ -1059,7 +1072,7 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	account_fm_log(&c->fm, eb);
 	{
 		int32_t wov = 0;
-		memcpy(&wov, c->h_eb[set] + 1, 4);
+		memcpy(&wov, c->h_evblock[set] + kEvOverflowOff, 4);
 		if (wov) {  // cannot happen (cap is the worst case); reported rather than ignored
 			snprintf(g_err, sizeof(g_err), "window table overflow");
 			return TFREC_AMD_E_STATE;

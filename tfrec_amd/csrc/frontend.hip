@@ -478,7 +478,8 @@ hipError_t launch_decim10(hipStream_t st, const uint8_t *iq, size_t stride, int 
 			  const uint8_t *tail_in, uint8_t *tail_out, uint32_t *out, size_t out_stride)
 {
 	const long n_out = (long)n_blocks * (TFREC_AMD_BLOCK_BYTES / 2);  // complex samples at 1.536 MS/s
-	dim3 grid((unsigned)((n_out + kT10 - 1) / kT10), n_streams);
+	static_assert(kBlockDec * 4 % kT10 == 0, "decim10_kernel has no partial tiles: a block is a whole number of them");
+	dim3 grid((unsigned)(n_out / kT10), n_streams);
 	hipLaunchKernelGGL(decim10_kernel, grid, dim3(kThreads10), 0, st, iq, stride, n_out, tail_in, tail_out, out, out_stride);
 	return hipGetLastError();
 }

@@ -53,6 +53,9 @@ def _load():
         lib.iqgen_stream_rate.restype = C.c_int
         lib.iqgen_stream_rate.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.POINTER(Truth), C.c_int, C.c_int]
+        lib.iqgen_stream_ex.restype = C.c_int
+        lib.iqgen_stream_ex.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.POINTER(Truth), C.c_int, C.c_int, C.c_int]
         lib.iqgen_batch.restype = C.c_int
         lib.iqgen_batch.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib = lib
@@ -60,14 +63,16 @@ def _load():
 
 
 def gen_stream(seed: int, stream: int, n_blocks: int, proto_mask: int = 0x1F, noise_q8: int = 256,
-               with_truth: bool = False, rate_mult: int = 1):
+               with_truth: bool = False, rate_mult: int = 1, corrupt_every: int = 0):
     """One stream of ``n_blocks`` blocks of 65536*rate_mult bytes -> uint8 array (and the planted bursts).
-    rate_mult 10 = the 15.36 MS/s input of BASELINE config 5."""
+    rate_mult 10 = the 15.36 MS/s input of BASELINE config 5.  corrupt_every = c > 0: every c-th burst carries a planted
+    fault (wrong checksum / right checksum but a field the decoder's sanity test rejects / frame cut short, in turn)."""
     lib = _load()
     out = np.empty(n_blocks * BLOCK_BYTES * rate_mult, dtype=np.uint8)
     cap = 4096
     truth = (Truth * cap)()
-    n = lib.iqgen_stream_rate(seed, stream, n_blocks, proto_mask, noise_q8, out.ctypes.data, truth, cap, rate_mult)
+    n = lib.iqgen_stream_ex(seed, stream, n_blocks, proto_mask, noise_q8, out.ctypes.data, truth, cap, rate_mult,
+                            corrupt_every)
     if not with_truth:
         return out
     recs = []

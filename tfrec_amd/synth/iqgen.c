@@ -250,8 +250,31 @@ typedef struct {
 static const int baud_tab[5] = { 38400, 17240, 9600, 8842, 6000 };
 
 /* returns burst length in samples; writes Q16 signal into si/sq[start..start+len) */
+/* Planted faults (tests of the decoders' acceptance verdicts through the whole path; no random numbers are drawn, so the
+ * signal of every other burst stays what it was): 1 = the checksum byte(s) do not match, 2 = checksum right but a field
+ * the decoder's sanity test looks at is wrong (TFA_1: tfa1.cpp:66-73 wants r[9] == 0x56; TX22: tfa2.cpp:76 wants the 0xa
+ * nibble; WHB: a type whb.cpp:50-62 does not know; TFA_2/3 have no such test: a payload byte changed under a stale CRC),
+ * 3 = the frame cut short by three bytes */
+static int corrupt_frame(int proto, uint8_t *f, int nbytes, int mode)
+{
+	if (mode == 1) {
+		f[nbytes - 1] ^= 0x5a;
+	} else if (mode == 2) {
+		switch (proto) {
+		case 0: f[9] = 0x55; f[10] = crc8_31(f + 2, 8); break;
+		case 1:
+		case 2: f[4] ^= 0x10; break;
+		case 3: f[2] = (uint8_t)(0xb0 | (f[2] & 0x0f)); f[nbytes - 1] = crc8_31(f + 2, nbytes - 3); break;
+		default: f[5] = 0x05; break;
+		}
+	} else if (mode == 3 && nbytes > 6) {
+		nbytes -= 3;
+	}
+	return nbytes;
+}
+
 static int64_t synth_burst(rng_t *r, work_t *w, int proto, int64_t start, int64_t total, int32_t *si, int32_t *sq,
-			   iqgen_truth_t *tr, int64_t fs)
+			   iqgen_truth_t *tr, int64_t fs, int corrupt)
 {
 	const int64_t FS = fs;
 	uint8_t frame[64];
@@ -261,7 +284,7 @@ static int64_t synth_burst(rng_t *r, work_t *w, int proto, int64_t start, int64_
 	memset(frame, 0, sizeof(frame));
 	switch (proto) {
 	case 0:
-		nbytes = frame_tfa1(r, frame);
+		nbytes = corrupt_frame(proto, frame, frame_tfa1(r, frame), corrupt);
 		for (int i = 0; i < 200; i++) bits[nb++] = 0;
 		put_bits_lsb(bits, &nb, frame, nbytes);
 		for (int i = 0; i < 48; i++) bits[nb++] = 0;
@@ -269,7 +292,7 @@ static int64_t synth_burst(rng_t *r, work_t *w, int proto, int64_t start, int64_
 	case 1:
 	case 2:
 	case 3: {
-		nbytes = proto == 3 ? frame_tx22(r, frame) : frame_tfa23(r, frame);
+		nbytes = corrupt_frame(proto, frame, proto == 3 ? frame_tx22(r, frame) : frame_tfa23(r, frame), corrupt);
 		int pre = proto == 1 ? 4 : (proto == 2 ? 12 : 8);
 		for (int i = 0; i < pre; i++) { bits[nb++] = 1; bits[nb++] = 0; }
 		put_bits_msb(bits, &nb, frame, nbytes);
@@ -277,7 +300,7 @@ static int64_t synth_burst(rng_t *r, work_t *w, int proto, int64_t start, int64_
 		break;
 	}
 	default: {
-		nbytes = frame_whb(r, frame);
+		nbytes = corrupt_frame(proto, frame, frame_whb(r, frame), corrupt);
 		uint8_t d[1024];
 		size_t nd = 0;
 		for (int i = 0; i < 200; i++) d[nd++] = 1;
@@ -375,8 +398,18 @@ static void quantise(rng_t *r, const int32_t *si, const int32_t *sq, int64_t n, 
  * delivers; 10: the 15.36 MS/s input of BASELINE config 5 -- same recipe, every duration in samples scaled).
  * proto_mask: bit p enables protocol p (0..4).  noise_q8: noise sigma in 1/256 LSB (256 = 1.0 LSB).  Returns the
  * number of planted bursts. */
+int iqgen_stream_ex(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, int noise_q8, uint8_t *out,
+		    iqgen_truth_t *truth, int truth_cap, int rate_mult, int corrupt_every);
+
 int iqgen_stream_rate(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, int noise_q8, uint8_t *out,
 		      iqgen_truth_t *truth, int truth_cap, int rate_mult)
+{
+	return iqgen_stream_ex(seed, stream, n_blocks, proto_mask, noise_q8, out, truth, truth_cap, rate_mult, 0);
+}
+
+/* corrupt_every = c > 0: bursts 0, c, 2c, ... carry a planted fault (corrupt_frame modes 1, 2, 3 in turn) */
+int iqgen_stream_ex(uint64_t seed, uint32_t stream, int n_blocks, int proto_mask, int noise_q8, uint8_t *out,
+		    iqgen_truth_t *truth, int truth_cap, int rate_mult, int corrupt_every)
 {
 	rng_t r, rn;
 	rng_seed(&r, seed, stream);
@@ -396,7 +429,8 @@ int iqgen_stream_rate(uint64_t seed, uint32_t stream, int n_blocks, int proto_ma
 			while (!(proto_mask & (1 << proto)))
 				proto = (proto + 1) % 5;
 			iqgen_truth_t tr;
-			int64_t len = synth_burst(&r, &w, proto, pos, limit, si, sq, &tr, fs);
+			const int fault = (corrupt_every > 0 && nt % corrupt_every == 0) ? 1 + (nt / corrupt_every) % 3 : 0;
+			int64_t len = synth_burst(&r, &w, proto, pos, limit, si, sq, &tr, fs, fault);
 			if (len < 0)
 				break;
 			if (truth && nt < truth_cap)
