@@ -73,7 +73,7 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float):
+def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float, all_cores: bool = True):
     """Time the reference CPU path, 1 thread, on a bounded sample of the same workload.
 
     kind "reference": the real reference hot path (oracle/_ref/ref_driver, compiled from /root/reference
@@ -115,6 +115,8 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
                            port_value=round(port, 3))
             except Exception as e:  # keep the port number
                 res["reference_error"] = str(e)[:200]
+    if not all_cores:
+        return res
     # (ii) of SURVEY 8(d): one stream per thread over all host cores (OpenMP inside the C restatement)
     try:
         ncpu = usable_cores()
@@ -199,9 +201,10 @@ def main():
     ap.add_argument("--parity-streams", type=int, default=-1,
                     help="streams of the first batch checked against the CPU oracle: -1 = all at N=1, 128 spread over the "
                          "batch per rank at N>1; 0 = none")
-    ap.add_argument("--parity-after-streams", type=int, default=64,
+    ap.add_argument("--parity-after-streams", type=int, default=0,
                     help="streams of the batch AFTER the timed region checked against the oracle continued over all "
-                         "repetitions of the input (a quarter of it per rank at N>1; needs --parity-streams != 0)")
+                         "repetitions of the input (0 = 256 on runs of up to 32 batches, down to 64 on long ones; a quarter of "
+                         "it per rank at N>1; needs --parity-streams != 0)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="backend of the barrier / scalar reduces at N>1 (the data path has no collective)")
     ap.add_argument("--same-device", action="store_true", help="tests: every rank uses cuda:0")
@@ -209,6 +212,9 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short secondary measurements of BASELINE configs[1] and configs[4] (N=1 only)")
     ap.add_argument("--depth", type=int, default=4, help="batches kept in the submit/drain FIFO (1..4)")
+    ap.add_argument("--ramp", type=int, default=int(os.environ.get("TFREC_BENCH_RAMP", "0")),
+                    help="caller-side submit policy while an EMPTY pipeline fills: the FIFO is filled to `ramp` batches at once and "
+                         "grows by one per drain up to --depth (0 = fill it to --depth at once)")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
                          "(secondary measurement; the default line stays config 2)")
@@ -328,7 +334,8 @@ def main():
         n_ev = 0
         queued = 0
         for k in range(n_steps):
-            while queued < n_steps and queued - k < depth:
+            d_k = depth if a.ramp <= 0 else min(depth, a.ramp + k)
+            while queued < n_steps and queued - k < d_k:
                 r.submit(d_iq if src is None else src)
                 queued += 1
             n_ev += len(r.drain())
@@ -365,7 +372,9 @@ def main():
         reps_before = (1 if parity_ok is not None else 0) + a.warmup + a.steps
         r.submit(d_iq)
         last = r.drain()
-        want_n = min(n_streams, a.parity_after_streams if world == 1 else max(8, a.parity_after_streams // 4))
+        # (the oracle has to run every checked stream over ALL repetitions: 256 streams on the driver's short line, fewer on long ones)
+        after_n = a.parity_after_streams if a.parity_after_streams > 0 else max(64, min(256, 256 * 32 // max(1, reps_before)))
+        want_n = min(n_streams, after_n if world == 1 else max(8, after_n // 4))
         pick = np.unique(np.linspace(0, n_streams - 1, want_n).round().astype(np.int64))
         src = np.unique(pick % unique)
         t_or = time.perf_counter()
@@ -398,6 +407,7 @@ def main():
     fm = r.fm_stats()
     fm_bad = shard.sum_over_ranks(fm["host_mismatch"], red_dev)
 
+    mem_tables = r.memory()  # before the PCIe leg: tfrec_amd_submit_host grows one input staging buffer per FIFO set on demand
     # ---- PCIe-inclusive leg: the same batch from page-locked host memory through the FIFO (never `value`)
     h2d = None
     if a.h2d_steps > 0 and world == 1:
@@ -432,10 +442,16 @@ def main():
     if world == 1 and not a.no_extra_configs and not a.input_10x and (n_streams, n_blocks, a.types) == (1024, 48, 0x2F):
         from oracle import oracle as O
 
-        def side(name, xs, xb, xt, x10, steps):
+        def side(name, xs, xb, xt, x10, steps, xthresh=None, gen=None, cpu_ref=False, want_kernels=()):
+            """One secondary leg: its own context, parity gate on fresh state (every distinct stream against the oracle),
+            then `steps` timed batches through the FIFO.  gen(xu, xb) -> the leg's distinct streams (default: the recipe of the
+            main line, seed 2000); xthresh: -t of the leg; cpu_ref: time the real reference's CPU path on the same stream."""
             xr = 10 if x10 else 1
+            xth = a.thresh if xthresh is None else xthresh
             xu = min(xs, 16)
-            if x10:
+            if gen is not None:
+                xh = gen(xu, xb)
+            elif x10:
                 xh = np.stack([synth.gen_stream(2000, k, xb, 0x1F, 256, rate_mult=10) for k in range(xu)])
             else:
                 xh = synth.gen_batch(2000, 0, xu, xb)
@@ -443,49 +459,82 @@ def main():
             xdu = torch.from_numpy(xh).to(dev)
             for s0 in range(0, xs, xu):
                 xd[s0:s0 + min(xu, xs - s0)].copy_(xdu[:min(xu, xs - s0)])
-            with api.Receiver(xs, xt, a.thresh, 0, device=dev_index, max_blocks=xb, max_events=max(4096, xs * 256),
-                              input_10x=x10) as xr_:
+            with api.Receiver(xs, xt, xth, 0, device=dev_index, max_blocks=xb, max_events=max(4096, xs * 256),
+                              input_10x=x10, timing=bool(want_kernels)) as xr_:
                 xr_.submit(xd)
                 first = xr_.drain()
                 ok = True
                 minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
+                n_want = 0
                 for k in range(xu):  # every distinct stream of the leg's batch
-                    o = O.Oracle(xt, a.thresh, 0)
+                    o = O.Oracle(xt, xth, 0)
                     if x10:
                         o.process_s16(O.decim10(xh[k]))
                     else:
                         o.process(xh[k])
                     want = sorted(e for e in o.events_full() if e[2] >= minb[e[0]] and not (e[0] == 3 and e[2] >= 64)
                                   and not (e[0] == 4 and e[2] > 60))
+                    n_want += len(want)
                     ok = ok and sorted(api.event_tuples_full(first, k)) == want
+                    if xth == 0:  # auto threshold (fm_demod.cpp:58-73): where it ended is part of the result
+                        ok = ok and xr_.thresh(k) == o.thresh()
                 q = 0
                 for k in range(3):  # warm-up
                     xr_.submit(xd)
                     xr_.drain()
                 torch.cuda.synchronize(dev)
                 tx = time.perf_counter()
+                kk = {}
                 for k in range(steps):
                     while q < steps and q - k < depth:
                         xr_.submit(xd)
                         q += 1
                     xr_.drain()
+                    if want_kernels:
+                        tm = xr_.timings()
+                        for nm in want_kernels:
+                            kk.setdefault(nm, []).append(tm[nm])
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - tx
             xalg = algorithmic_floor_ms(xs, xb, xt) if not x10 else None
-            extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, input_10x=x10, steps=steps, parity_ok=ok,
-                               parity_streams_checked=xu,
+            extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, thresh=xth, input_10x=x10, steps=steps, parity_ok=ok,
+                               parity_streams_checked=xu, parity_events_checked=n_want,
                                ms_per_step=round(dt / steps * 1e3, 4),
                                hbm_frac=round(2.0 * xs * xb * SAMPLES_PER_BLOCK * xr / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
                                algorithmic_valu_floor_ms=(xalg["ms"] if xalg else None),
                                value=round(xs * xb * SAMPLES_PER_BLOCK * xr * steps / dt / 1e6, 1), unit="MSamples/s")
+            for nm, v in kk.items():
+                extra[name][nm] = round(float(np.mean(v)), 4)
+            if cpu_ref and a.cpu_budget > 0:  # (64 streams of the leg's recipe back to back: seconds, not milliseconds, of CPU work)
+                extra[name]["cpu_baseline"] = cpu_baseline(synth.gen_batch(2000, 0, 64, xb), xt, xth, a.cpu_budget, all_cores=False)
+            return extra[name]
+
+        def noisy_tail(xu, xb):
+            """the main recipe with the LAST distinct stream at noise sigma 16 LSB: |I| + |Q| of the decimated samples stays
+            above -t 500, the stream's trigger windows never close (duty 1.0): the worst case of every per-stream serial chain"""
+            xh = synth.gen_batch(2000, 0, xu, xb)
+            xh[xu - 1] = synth.gen_stream(2000, xu - 1, xb, 0x1F, 16 * 256)
+            return xh
 
         try:
+            # the reference's own operating points (BASELINE.md section 2) ...
+            side("configs[0]: one 1.536 MS/s stream, TFA_1 only (-T 1), auto threshold (the reference's default flags)", 1, 48, 0x01,
+                 False, 30, xthresh=0, cpu_ref=True)
             side("configs[1]: one 1.536 MS/s stream, TFA_1/2/3 (-T 7)", 1, 48, 0x07, False, 30)
             # (512 streams: 16 GB of input per batch -- with 256 the 10:1 stage hides behind the demodulator chains, whose length
             # does not shrink with the batch; BASELINE.json names no stream count for this configuration)
             side("configs[4]: 512 streams at 15.36 MS/s through the 10:1 front end, all five protocols", 512, 48, 0x2F, True, 8)
             # the streaming kernels without the WHB chain's serial floor: configs[2]'s batch with the demodulators of configs[1]
             side("1024 streams x TFA_1/2/3 (-T 7): no WHB chain", 1024, 48, 0x07, False, 12)
+            # ... the two ends of the trigger duty cycle: never triggered (BASELINE.md section 2, row 4: the front end and the
+            # window scan are all that runs -- the streaming kernel's own HBM fraction inside the whole path) ...
+            side("1024 streams x 5 protocols, -t 30000: never triggered (front end only)", 1024, 48, 0x2F, False, 12, xthresh=30000,
+                 want_kernels=("frontend_ms",))
+            # ... and the tail case: one stream in 16 (64 of 1024) with its windows open all the time (duty 1.0): every
+            # per-stream serial chain of the batch is as long as its longest stream
+            t_ = side("1024 streams x 5 protocols, 64 of them at trigger duty 1.0 (noise above -t 500)", 1024, 48, 0x2F, False, 12,
+                      gen=noisy_tail, want_kernels=("whb_verify_ms", "whb_demod_ms", "coop_slicer_ms", "tfa1_coop_slicer_ms"))
+            t_["whb_verify_over_period"] = round(t_["whb_verify_ms"] / t_["ms_per_step"], 3)
         except Exception as e:  # informative legs: never fail the line for them
             extra["error"] = str(e)[:200]
 
@@ -497,7 +546,7 @@ def main():
         # (whb_decode / whb_commit: since they run in the tail of whb_demod_kernel those two timing fields are empty)
         kms = {k[:-3] + "_kernel": float(np.mean(v)) for k, v in kt.items()
                if k not in ("chains_ms", "total_ms", "whb_decode_ms", "whb_commit_ms")}
-        dom_name = max(kms, key=kms.get)
+        dom_name = max(kms, key=kms.get)  # (replaced below by the kernel that is longest ALONE on the chip, where profiled)
         dom_ms = kms[dom_name]
         alg_bytes = 2.0 * samples_per_step_gpu  # 2 B per complex input sample, one launch = one batch
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -508,10 +557,24 @@ def main():
         traffic = traffic_total = prof_ms = traffic_source = None
         valu = None
         same_workload = (n_streams, n_blocks, a.types, rate) == (1024, 48, 0x2F, 1)
-        ptag = next((t for t in ("r04_final", "r04_mid", "r03_final", "r03_mid")
+        ptag = next((t for t in ("r05_final", "r05_mid", "r04_final", "r04_mid", "r03_final", "r03_mid")
                      if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
         chain_floor = fe_alone = chain_kernel = None
+        utilisation = None
         if ptag and same_workload:
+            try:  # the dominant kernel = the one with the longest duration ALONE on the chip (committed profile), timed live
+                vj0 = json.load(open(os.path.join(ROOT, "profiles", ptag + "_valu.json")))["kernels"]
+                alone = {}
+                for kn, kv in vj0.items():
+                    base = kn.split("<")[0]
+                    alone[base] = max(alone.get(base, 0.0), kv.get("kernel_ms_alone") or 0.0)  # (template instances: the longest)
+                cand_ = [kn for kn in sorted(alone, key=alone.get, reverse=True) if kn in kms and kms[kn] > 0]
+                if cand_:
+                    dom_name = cand_[0]
+                    dom_ms = kms[dom_name]
+                    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+            except Exception:
+                pass
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_traffic.json")))
                 traffic = tj["kernels"].get(dom_name, {}).get("hbm_bytes")
@@ -539,21 +602,26 @@ def main():
                     "roof_ms": vj["valu_roof_ms"], "busy_ms_counters": vj["valu_busy_ms_counters"],
                     "salu_roof_ms": vj["salu_roof_ms"], "salu_busy_ms_counters": vj["salu_busy_ms_counters"],
                     "frac": round(vj["valu_roof_ms"] / (elapsed / a.steps * 1e3), 4),
-                    # the roof the pipeline sits on: quad-cycles with an instruction of ANY kind in flight, over the 1024 SIMDs
-                    # (a UTILISATION figure, not a roofline: quad-cycles with an instruction of ANY kind in flight, of the
-                    # instructions this implementation issues, spread over the 1024 SIMDs)
-                    "issue_busy_ms": vj.get("issue_roof_ms"),
-                    "issue_busy_frac": (round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4) if vj.get("issue_roof_ms") else None),
                     "sum_of_kernel_ms_alone": vj["sum_of_kernel_ms_alone"],
                     "source": "profiles/%s_valu.json (builder's rocprofv3 --pmc passes of this command; NOT measured in this run)" % ptag,
                     "how": "VALU wave-instructions of one batch by class (rocprofv3 --pmc, profiles/%s_pmc_mix.txt) x the measured "
                            "time per instruction and SIMD (profiles/ubench/valu_issue.hip -> profiles/%s_valu_issue.jsonl: kernel time / "
                            "(instructions per wave x waves per SIMD), 1.6-2.1 ns = 4 cycles) / 1024 SIMDs; busy_ms_counters = "
                            "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), the same roof from the counters alone; frac = "
-                           "roof_ms / ms_per_step; issue_busy_ms = SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x 2.4 GHz): every kind of "
-                           "instruction this implementation issues, issue_busy_frac = that / ms_per_step; per kernel: "
-                           "profiles/%s_valu.json" % (ptag, ptag, ptag),
+                           "roof_ms / ms_per_step; per kernel: profiles/%s_valu.json" % (ptag, ptag, ptag),
                 }
+                if vj.get("issue_roof_ms"):
+                    utilisation = {
+                        "issue_busy_ms": vj["issue_roof_ms"],
+                        "issue_busy_over_period": round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4),
+                        "note": "NOT a roofline and not a capacity: sum over the batch's kernels of SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x "
+                                "2.4 GHz) = wave-quad-cycles with an instruction of any kind in flight.  Waves of one SIMD overlap (a vector "
+                                "and a scalar instruction of two waves take 0.70-0.78 x their sum, profiles/r04_mixed_issue.jsonl), and the "
+                                "front end ALONE already reads more than 100 % by this measure (inst_active_ms > kernel_ms_alone in "
+                                "profiles/%s_valu.json): the period has followed this sum within 5 %% for four rounds, with >= 20 %% of slack "
+                                "in it.  What bounds the path is in `roofline` (hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms)." % ptag,
+                        "source": "profiles/%s_valu.json (builder's rocprofv3 --pmc passes; NOT measured in this run)" % ptag,
+                    }
                 # the serial floor: the dominant chain kernel ALONE on the chip (serial per stream; consecutive batches'
                 # launches of it run one after the other) and the only kernel that streams the input, alone
                 kj = vj.get("kernels", {})
@@ -610,6 +678,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                # `kernel` is the kernel with the longest duration ALONE on the chip (a serial per-stream chain that does not
+                # stream the input: its `frac` prices the batch's algorithmic bytes against ITS duration, as the contract asks);
+                # the honest figure for the path is whole_path_frac = algorithmic bytes / batch period / peak
+                "headline_frac": "whole_path_frac",
                 # the dominant kernel's duration: live HIP events on its stream (includes its wait for the chip beside the
                 # other streams' kernels) | average of the same kernel in the committed kernel trace, per batch
                 "kernel_ms_hip_events": round(dom_ms, 4), "kernel_ms_profiles": prof_ms,
@@ -634,13 +706,17 @@ def main():
                 "gpu_ms_per_step": round(float(np.mean(kt.get("total_ms", [0.0]))), 4),
                 "speculation_stats": r.stats(),
                 "pipeline_streams": r.layout(),
-                "context_memory": r.memory(),
+                # device_bytes: what a context fed from device memory holds; with_host_staging: after the
+                # PCIe leg, + FIFO-depth staging copies of the batch (tfrec_amd_submit_host) -- round 4's line reported only this
+                "context_memory": dict(mem_tables, device_bytes_with_host_staging=r.memory()["device_bytes"]),
             },
         }
         if a.cpu_budget > 0 and world == 1 and rate == 1:
             out["cpu_baseline"] = cpu_baseline(host[: min(unique, 256)], a.types, a.thresh, a.cpu_budget)
         if h2d is not None:
             out["h2d_included"] = h2d
+        if utilisation:
+            out["utilisation"] = utilisation
         if extra:
             out["other_configs"] = extra
         print(json.dumps(out), flush=True)

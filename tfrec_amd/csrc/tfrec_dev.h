@@ -241,6 +241,9 @@ struct WinTables {
 	int32_t *segfix;        // [chains*segcap] repair run: slots rewritten | kSegConverged
 	BiquadEnd *segend3;     // [chains*segcap] ... second repair run (started from segend2 of the segment before)
 	int32_t *segfix2;       // [chains*segcap] second repair run: slots rewritten | kSegConverged | kSegRan (0: not run)
+	size_t segcnt_bytes;
+	int32_t *segcnt;        // [chains*segcap] fused speculate + repair launch: speculative runs finished at the boundary in front of
+	                        // the segment (0..2), zeroed per submit
 	int32_t *overflow;      // set when a chain found more than cap windows
 	unsigned long long *stats;  // [8] tfrec_amd_stats
 	const uint32_t *prevdec;  // [n_streams] the decimated sample before this submit's first one (front end)
@@ -293,6 +296,8 @@ struct PipeCtl {
 	// TFA_2 family, stage B split: once the long windows' heads are sliced (cs), the cooperative slicers of their tails
 	// run on cz beside the short windows' slicers on cs (nullptr: one after the other on cs)
 	hipStream_t cz;
+	hipStream_t mz;            // the TFA_1 peak pieces (mark_kernel) beside the short windows' slicers on t1 (TFREC_AMD_MARK_OWN), or nullptr
+	hipEvent_t ev_mark, ev_t1go;
 	hipStream_t fq;            // the discriminator pass's own stream (TFREC_AMD_FMDEV_OWN), or nullptr: at the head of k2
 	hipEvent_t ev_heads, ev_coop;
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
@@ -311,9 +316,11 @@ constexpr int kNQueues = 8;
 // chains whose commit found a window sliced under a wrong last_bit_idx assumption (commit_wave_kernel takes them)
 constexpr int kDeferQueue = kNQueues;
 #ifndef TFREC_AMD_SEG_SLOTS
-#define TFREC_AMD_SEG_SLOTS 128
+#define TFREC_AMD_SEG_SLOTS 256
 #endif
-constexpr int kSegSlots = TFREC_AMD_SEG_SLOTS;  // biquad segments: 128 in-window slots (>= 3700 samples: windows are >= 11 slots long)
+constexpr int kSegSlots = TFREC_AMD_SEG_SLOTS;  // biquad segments: 256 in-window slots (>= 7400 samples: windows are >= 11 slots long).  Round 5
+                                                // (profiles/r05_ab_segments.txt): 128 -> 256 with the same number of waves = a quarter fewer repair
+                                                // slots, the batch 2.5 % shorter; 512: no better (the passes stretch), 1024: 17 % worse
 constexpr int kSegConverged = 0x40000000, kSegRan = 0x20000000;
 constexpr int kLongWindow = 4096;  // samples; longer windows go to the wave-cooperative slicers (default).  The
                                    // lane-per-window slicers cost fewer instructions per sample (64 windows share a
