@@ -212,9 +212,6 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short secondary measurements of BASELINE configs[1] and configs[4] (N=1 only)")
     ap.add_argument("--depth", type=int, default=4, help="batches kept in the submit/drain FIFO (1..4)")
-    ap.add_argument("--ramp", type=int, default=int(os.environ.get("TFREC_BENCH_RAMP", "0")),
-                    help="caller-side submit policy while an EMPTY pipeline fills: the FIFO is filled to `ramp` batches at once and "
-                         "grows by one per drain up to --depth (0 = fill it to --depth at once)")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
                          "(secondary measurement; the default line stays config 2)")
@@ -334,8 +331,7 @@ def main():
         n_ev = 0
         queued = 0
         for k in range(n_steps):
-            d_k = depth if a.ramp <= 0 else min(depth, a.ramp + k)
-            while queued < n_steps and queued - k < d_k:
+            while queued < n_steps and queued - k < depth:
                 r.submit(d_iq if src is None else src)
                 queued += 1
             n_ev += len(r.drain())

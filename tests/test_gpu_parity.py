@@ -250,44 +250,6 @@ def test_submits_in_flight_fifo():
         assert a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("groups", ["3", "16"])
-def test_stream_groups_same_events_same_order(groups, monkeypatch):
-    """Sub-batches inside a submit (TFREC_AMD_GROUPS: the context is a shell over G inner contexts of consecutive streams
-    whose kernels are queued group after group on the shared HIP streams): the drained events -- content, `seq`, order --
-    are byte for byte those of the ungrouped context, with four submits in flight, ragged submit lengths, an uneven split
-    (25 streams over 3 groups: 9 + 8 + 8) and one stream per group and more (16 groups)."""
-    import torch
-
-    n_streams = 25
-    iq = synth.gen_batch(41, 3, n_streams, 40)
-    cuts = ((0, 8), (8, 9), (9, 20), (20, 30), (30, 40))
-    dev = [torch.from_numpy(np.ascontiguousarray(iq[:, a * 65536:b * 65536])).cuda() for a, b in cuts]
-    out = {}
-    for g in ("1", groups):
-        monkeypatch.setenv("TFREC_AMD_GROUPS", g)
-        with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=11, all_flushes=True, timing=True) as r:
-            got, q = [], 0
-            for k in range(len(dev)):
-                while q < len(dev) and q - k < api.FIFO_DEPTH:
-                    r.submit(dev[q])
-                    q += 1
-                got.append(r.drain())
-            with pytest.raises(RuntimeError):  # the FIFO rule holds for the shell too
-                for k in range(api.FIFO_DEPTH + 1):
-                    r.submit(dev[0])
-            t = r.timings()
-            assert t["frontend_ms"] > 0 and r.memory()["device_bytes"] > 0 and r.stats()["biquad_segments"] > 0
-            for s in (0, 8, 9, 24):
-                assert np.array_equal(r.decimated(s, 8192), r.decimated(s, 8192))
-            out[g] = got
-    for a, b in zip(out["1"], out[groups]):
-        assert len(a) > 0 and a.tobytes() == b.tobytes()
-    ev = np.concatenate(out[groups])
-    ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
-    for s in range(n_streams):
-        check_stream(ev, s, oracle_events(iq[s], 0x2F, 500))
-
-
 def test_drain_fetches_events_beyond_the_copy_queued_at_submit(monkeypatch):
     """The submit queues the device-to-host copy of a GUESSED number of events (twice the last drain's count); a batch
     with more events than that must still deliver all of them, in the same order."""
@@ -551,7 +513,7 @@ def test_config2_full_size_every_stream():
         total = _all_streams_equal(ev, iq, 0x2F, 500)
         assert total > 80 * n_streams
         assert r.fm_stats()["host_mismatch"] == 0
-        assert r.stats()["biquad_segments"] > 100 * n_streams
+        assert r.stats()["biquad_segments"] > 40 * n_streams  # (256-slot segments: ~46 per stream and submit)
 
 
 def test_hostile_and_degenerate_inputs_over_ragged_submits():
@@ -682,9 +644,8 @@ def _steady_inputs():
     return _STEADY["batches"], _STEADY["orc"]
 
 
-@pytest.mark.parametrize("force_fail,groups", [(0, None), (3, None), (0, "4"), (3, "2")],
-                         ids=["plain", "whb_every_third_stream_redone", "four_stream_groups", "two_groups_whb_redone"])
-def test_config2_steady_state_five_batches_vs_oracle(force_fail, groups, monkeypatch):
+@pytest.mark.parametrize("force_fail", [0, 3], ids=["plain", "whb_every_third_stream_redone"])
+def test_config2_steady_state_five_batches_vs_oracle(force_fail, monkeypatch):
     """BASELINE configs[2] in the state the benchmark times it: five different 1024 x 48-block batches through ONE
     context with four submits in flight at all times (submit k+4 is queued before submit k is drained), all flushes, every
     stream of every batch against the oracle run over the 240 blocks as one stream.  Second variant: every third
@@ -695,8 +656,6 @@ def test_config2_steady_state_five_batches_vs_oracle(force_fail, groups, monkeyp
 
     if force_fail:
         monkeypatch.setenv("TFREC_AMD_WHB_FORCE_FAIL", str(force_fail))
-    if groups:  # sub-batches inside every submit (shell over `groups` inner contexts on shared HIP streams)
-        monkeypatch.setenv("TFREC_AMD_GROUPS", groups)
     batches, orc = _steady_inputs()
     n_streams, n_blocks = 1024, 48
     dev = [torch.from_numpy(np.ascontiguousarray(b)).to("cuda:0") for b in batches]

@@ -92,8 +92,6 @@ struct tfrec_amd_ctx {
 	hipEvent_t ev_pipe[kSets][7] = {};
 	hipStream_t fq = nullptr;                    // PipeCtl::fq (TFREC_AMD_FMDEV_OWN)
 	hipStream_t cq = nullptr;                    // the drain's copies, when not on cp (TFREC_AMD_COPY_OWN)
-	hipStream_t mz = nullptr;                    // PipeCtl::mz (TFREC_AMD_MARK_OWN)
-	hipEvent_t ev_mark[kSets][2] = {};
 	hipStream_t cz = nullptr;                    // PipeCtl::cz (TFREC_AMD_COOP_STREAM)                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
 	// one set per submit in flight, like the front-end outputs: the window scan and the biquads of submit k+1 fill
@@ -166,14 +164,6 @@ struct tfrec_amd_ctx {
 	// TFREC_AMD_HOST_PROF=1: host-side time of the submit / drain calls, printed when the context is destroyed
 	double hp_submit = 0, hp_wait = 0, hp_copy = 0, hp_sort = 0, hp_gap = 0, hp_lat = 0, hp_s2s = 0;
 	long hp_n = 0, hp_gap_n = 0;
-	// Stream groups (sub-batches inside a submit): a context of many streams is a shell over `groups`
-	// inner contexts of n_streams / G consecutive streams each.  They share the shell's HIP streams (owned by group 0), and a
-	// submit queues group 0's kernels on them, then group 1's, ...: the groups enter the stage graph staggered, group 0 is
-	// through its last stage when group G-1 leaves the front end, and an empty pipeline fills in a G-th of the time.  State,
-	// tables and event buffers are per group (streams are independent: engine.cpp:46-94).
-	std::vector<tfrec_amd_ctx *> groups;
-	int stream_base = 0;        // inner context: index of its first stream in the caller's batch
-	bool owns_streams = true;   // inner contexts of group > 0 use group 0's HIP streams
 };
 
 namespace {
@@ -249,17 +239,6 @@ static void account_fm_log(FmTotals *t, const EventBuf &eb)
 	}
 }
 
-// the group of a shell context that holds `stream` (and the stream's index inside it); nullptr: out of range
-static tfrec_amd_ctx *group_of(tfrec_amd_ctx *c, int stream, int *local)
-{
-	for (auto *in : c->groups)
-		if (stream >= in->stream_base && stream < in->stream_base + in->cfg.n_streams) {
-			*local = stream - in->stream_base;
-			return in;
-		}
-	return nullptr;
-}
-
 extern "C" {
 
 const char *tfrec_amd_version(void) { return "tfrec_amd 0.1 (gfx950)"; }
@@ -293,16 +272,6 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 {
 	if (!c)
 		return TFREC_AMD_OK;
-	if (!c->groups.empty()) {  // a shell: the groups that borrow streams first, their owner (group 0) last
-		(void)hipSetDevice(c->cfg.device);
-		(void)hipDeviceSynchronize();
-		for (size_t g = c->groups.size(); g-- > 0;)
-			tfrec_amd_destroy(c->groups[g]);
-		delete c;
-		return TFREC_AMD_OK;
-	}
-	if (!c->owns_streams)  // (borrowed handles: the owner destroys them)
-		c->fs = c->cp = c->cs = c->cz = c->mz = c->fq = c->cq = c->k2 = c->kw = c->aux = c->t1 = c->vx = nullptr;
 	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_n)
 		fprintf(stderr, "tfrec_amd host time per batch: submit %.0f us, drain: wait %.0f + copy %.0f + sort %.0f us (%ld batches)\n",
 			1e6 * c->hp_submit / c->hp_n, 1e6 * c->hp_wait / c->hp_n, 1e6 * c->hp_copy / c->hp_n, 1e6 * c->hp_sort / c->hp_n,
@@ -342,12 +311,6 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	(void)hipFree(c->d_tcarry);
 	if (c->cz)
 		(void)hipStreamDestroy(c->cz);
-	if (c->mz)
-		(void)hipStreamDestroy(c->mz);
-	for (auto &row : c->ev_mark)
-		for (auto &e : row)
-			if (e)
-				(void)hipEventDestroy(e);
 	if (c->fq)
 		(void)hipStreamDestroy(c->fq);
 	if (c->cq)
@@ -400,8 +363,7 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 	return TFREC_AMD_OK;
 }
 
-// share != nullptr: an inner context of a stream group that uses `share`'s HIP streams instead of creating its own
-static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, tfrec_amd_ctx **out)
+int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 {
 	if (!cfg || !out)
 		return TFREC_AMD_E_INVAL;
@@ -429,7 +391,6 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 	if (!c)
 		return TFREC_AMD_E_NOMEM;
 	c->cfg = *cfg;
-	c->owns_streams = share == nullptr;
 	if (const char *fe = getenv("TFREC_AMD_FM_FLAG_EPS"))
 		c->fm_flag_eps = std::max(1e-9, atof(fe));
 	if (const char *cg = getenv("TFREC_AMD_COPY_GUESS_MIN"))
@@ -612,7 +573,7 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 		const size_t o_ckpt = carve(ck_chains * (size_t)T.slots * sizeof(double2));
 		const size_t o_sstart = carve(segs * sizeof(uint2)), o_vtotal = carve(chains * 4);
 		const size_t o_se1 = carve(segs * sizeof(BiquadEnd)), o_se2 = carve(segs * sizeof(BiquadEnd)), o_sfix = carve(segs * 4);
-		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4), o_scnt = carve(segs * 4);
+		const size_t o_se3 = carve(segs * sizeof(BiquadEnd)), o_sfix2 = carve(segs * 4);
 		const size_t o_cand = carve(n * (size_t)T.slots * 4), o_mark = carve(n * (size_t)T.slots * sizeof(MarkPiece));
 		T.whbrec_stride = (int32_t)(m_max / 64 + 2 * (size_t)T.cap + 2 + kWhbRecSlack);
 		const size_t o_wrec = carve(whb ? n * (size_t)T.whbrec_stride * sizeof(WhbStepRec) : 0), o_wfail = carve(whb ? n * 4 : 0);
@@ -642,8 +603,6 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 			T.segfix = (int32_t *)(b + o_sfix);
 			T.segend3 = (BiquadEnd *)(b + o_se3);
 			T.segfix2 = (int32_t *)(b + o_sfix2);
-			T.segcnt = (int32_t *)(b + o_scnt);
-			T.segcnt_bytes = segs * 4;
 			T.cand = (uint32_t *)(b + o_cand);
 			T.mark = (MarkPiece *)(b + o_mark);
 			T.whbrec = (WhbStepRec *)(b + o_wrec);
@@ -713,15 +672,7 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 			return dflt;
 		return prio_env[k] == 'h' ? prio_hi : (prio_env[k] == 'l' ? prio_lo : 0);
 	};
-	auto mkstream = [&](hipStream_t *st, int k, int dflt) {
-		if (share) {  // the group's streams are the owner's
-			static const size_t off[7] = { offsetof(tfrec_amd_ctx, fs), offsetof(tfrec_amd_ctx, cp), offsetof(tfrec_amd_ctx, cs), offsetof(tfrec_amd_ctx, t1),
-						       offsetof(tfrec_amd_ctx, aux), offsetof(tfrec_amd_ctx, k2), offsetof(tfrec_amd_ctx, kw) };
-			*st = *reinterpret_cast<const hipStream_t *>(reinterpret_cast<const char *>(share) + off[k]);
-			return hipSuccess;
-		}
-		return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(k, dflt));
-	};
+	auto mkstream = [&](hipStream_t *st, int k, int dflt) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(k, dflt)); };
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb;
@@ -775,19 +726,7 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 			rc = TFREC_AMD_E_HIP;
 		// TFREC_AMD_COOP_STREAM=1: a stream for the TFA_2 family's cooperative slicers (PipeCtl::cz).  It is the fifth of high
 		// priority: with the HIP default of four hardware queues per priority it shares one (GPU_MAX_HW_QUEUES >= 8 wanted).
-		// TFREC_AMD_MARK_OWN=1 (high) / 2 (normal priority): mark_kernel on a stream of its own beside the TFA_1 short-window slicers
-		if (share)
-			c->mz = share->mz;
-		else if (c->deep && rc == TFREC_AMD_OK && getenv("TFREC_AMD_MARK_OWN") && atoi(getenv("TFREC_AMD_MARK_OWN")) != 0 &&
-			 hipStreamCreateWithPriority(&c->mz, hipStreamNonBlocking, atoi(getenv("TFREC_AMD_MARK_OWN")) == 2 ? 0 : prio_hi) != hipSuccess)
-			rc = TFREC_AMD_E_HIP;
-		for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++)
-			for (auto &e : c->ev_mark[k])
-				if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
-					rc = TFREC_AMD_E_HIP;
-		if (share)
-			c->cz = share->cz;
-		else if (c->deep && rc == TFREC_AMD_OK && getenv("TFREC_AMD_COOP_STREAM") && atoi(getenv("TFREC_AMD_COOP_STREAM")) != 0 &&
+		if (c->deep && rc == TFREC_AMD_OK && getenv("TFREC_AMD_COOP_STREAM") && atoi(getenv("TFREC_AMD_COOP_STREAM")) != 0 &&
 		    hipStreamCreateWithPriority(&c->cz, hipStreamNonBlocking, atoi(getenv("TFREC_AMD_COOP_STREAM")) == 2 ? 0 : prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 		// The discriminator pass on a LOW-priority stream of its own (TFREC_AMD_FMDEV_OWN: 0 = at the head of k2, 1 = low
@@ -797,9 +736,7 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 		// hardware queues are otherwise unused, so the stream shares none (a fifth normal-priority stream would).
 		{
 			const int m = getenv("TFREC_AMD_FMDEV_OWN") ? atoi(getenv("TFREC_AMD_FMDEV_OWN")) : (c->fmdev_k2 ? 1 : 0);
-			if (share)
-				c->fq = share->fq;
-			else if (c->deep && rc == TFREC_AMD_OK && m > 0 && c->need_fmdev && c->fmdev_k2 &&
+			if (c->deep && rc == TFREC_AMD_OK && m > 0 && c->need_fmdev && c->fmdev_k2 &&
 			    hipStreamCreateWithPriority(&c->fq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
@@ -809,9 +746,7 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 		// (profiles/r04_ab_copy_stream.txt); the low pool's hardware queues hold only this stream and the discriminator's.
 		{  // (TFREC_AMD_COPY_OWN: 0 = on cp, 1 = low priority (default), 2 = normal, 3 = high)
 			const int m = getenv("TFREC_AMD_COPY_OWN") ? atoi(getenv("TFREC_AMD_COPY_OWN")) : 1;
-			if (share)
-				c->cq = share->cq;
-			else if (c->deep && rc == TFREC_AMD_OK && m > 0 &&
+			if (c->deep && rc == TFREC_AMD_OK && m > 0 &&
 			    hipStreamCreateWithPriority(&c->cq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
@@ -842,56 +777,6 @@ static int core_create(const tfrec_amd_config *cfg, const tfrec_amd_ctx *share, 
 		return rc;
 	}
 	*out = c;
-	return TFREC_AMD_OK;
-}
-
-#ifndef TFREC_AMD_DEFAULT_GROUPS
-#define TFREC_AMD_DEFAULT_GROUPS 1
-#endif
-constexpr int kDefaultGroups = TFREC_AMD_DEFAULT_GROUPS;
-// Stream groups of a context (TFREC_AMD_GROUPS overrides: 1 = none).  A group needs enough streams to fill the chip's
-// lane-per-window and wave-per-stream kernels by itself: at least 256.
-static int groups_for(const tfrec_amd_config *cfg)
-{
-	if (cfg->flags & TFREC_AMD_F_SERIAL_CHAINS)
-		return 1;
-	int g = cfg->n_streams >= 1024 ? kDefaultGroups : (cfg->n_streams >= 512 ? std::min(2, kDefaultGroups) : 1);
-	if (const char *e = getenv("TFREC_AMD_GROUPS"))
-		g = atoi(e);
-	return std::max(1, std::min(g, std::min(16, (int)cfg->n_streams)));
-}
-
-int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
-{
-	if (!cfg || !out)
-		return TFREC_AMD_E_INVAL;
-	*out = nullptr;
-	const int G = (cfg->n_streams >= 1 && cfg->n_streams <= 65535) ? groups_for(cfg) : 1;
-	if (G <= 1)
-		return core_create(cfg, nullptr, out);
-	tfrec_amd_ctx *sh = new (std::nothrow) tfrec_amd_ctx();
-	if (!sh)
-		return TFREC_AMD_E_NOMEM;
-	sh->cfg = *cfg;
-	const int base = cfg->n_streams / G, rem = cfg->n_streams % G;
-	int s0 = 0;
-	for (int g = 0; g < G; g++) {
-		tfrec_amd_config sub = *cfg;
-		sub.n_streams = base + (g < rem ? 1 : 0);
-		// a group holds a G-th of the streams: twice its share of the event capacity (the shell's drain reports an overflow
-		// of any group)
-		sub.max_events = (int32_t)std::min<long long>(cfg->max_events, std::max<long long>(4096, 2ll * cfg->max_events / G));
-		tfrec_amd_ctx *in = nullptr;
-		const int rc = core_create(&sub, g ? sh->groups[0] : nullptr, &in);
-		if (rc != TFREC_AMD_OK) {
-			tfrec_amd_destroy(sh);
-			return rc;
-		}
-		in->stream_base = s0;
-		s0 += sub.n_streams;
-		sh->groups.push_back(in);
-	}
-	*out = sh;
 	return TFREC_AMD_OK;
 }
 
@@ -985,9 +870,6 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.ev_kw = c->ev_pipe[set][3];
 		P.ev_fm = c->ev_pipe[set][4];
 		P.cz = c->cz;
-		P.mz = c->mz;
-		P.ev_mark = c->ev_mark[set][0];
-		P.ev_t1go = c->ev_mark[set][1];
 		P.fq = c->fq;
 		P.ev_heads = c->ev_pipe[set][5];
 		P.ev_coop = c->ev_pipe[set][6];
@@ -1105,23 +987,6 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 
 int tfrec_amd_submit_device(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int n_blocks, void *hip_stream)
 {
-	if (c && !c->groups.empty()) {  // group by group: group g's kernels are queued behind group g-1's on every stream
-		if (c->groups[0]->inflight >= kSets) {  // (refuse before anything is queued: the groups' FIFOs move together)
-			snprintf(g_err, sizeof(g_err), "%d submits are waiting to be drained: call tfrec_amd_drain_events first", kSets);
-			return TFREC_AMD_E_STATE;
-		}
-		for (size_t g = 0; g < c->groups.size(); g++) {
-			const int rc = tfrec_amd_submit_device(c->groups[g], d_iq ? (const uint8_t *)d_iq + (size_t)c->groups[g]->stream_base * stride : nullptr,
-							       stride, n_blocks, hip_stream);
-			if (rc != TFREC_AMD_OK) {
-				if (g > 0)  // some groups took the submit, this one did not: the shell cannot continue
-					for (auto *in : c->groups)
-						in->poisoned = true;
-				return rc;
-			}
-		}
-		return TFREC_AMD_OK;
-	}
 	const auto t0 = std::chrono::steady_clock::now();
 	const int rc = submit_common(c, d_iq, stride, n_blocks, hip_stream, false);
 	if (c)
@@ -1133,22 +998,6 @@ static int submit_host_impl(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride
 
 int tfrec_amd_submit_host(tfrec_amd_ctx *c, const uint8_t *h_iq, size_t stride, int n_blocks)
 {
-	if (c && !c->groups.empty()) {
-		if (c->groups[0]->inflight >= kSets) {
-			snprintf(g_err, sizeof(g_err), "%d submits are waiting to be drained: call tfrec_amd_drain_events first", kSets);
-			return TFREC_AMD_E_STATE;
-		}
-		for (size_t g = 0; g < c->groups.size(); g++) {
-			const int rc = tfrec_amd_submit_host(c->groups[g], h_iq ? h_iq + (size_t)c->groups[g]->stream_base * stride : nullptr, stride, n_blocks);
-			if (rc != TFREC_AMD_OK) {
-				if (g > 0)
-					for (auto *in : c->groups)
-						in->poisoned = true;
-				return rc;
-			}
-		}
-		return TFREC_AMD_OK;
-	}
 	const auto t0 = std::chrono::steady_clock::now();
 	const int rc = submit_host_impl(c, h_iq, stride, n_blocks);
 	if (c)
@@ -1202,10 +1051,8 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 {
 	if (!c)
 		return TFREC_AMD_E_INVAL;
-	if (!c->groups.empty())  // (the groups share their streams)
-		return tfrec_amd_sync(c->groups[0]);
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->mz, c->fq, c->cq, c->aux, c->vx, c->t1, c->cp })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->fq, c->cq, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;
@@ -1216,18 +1063,6 @@ int tfrec_amd_pending_events(tfrec_amd_ctx *c, int *n)
 	if (!c || !n)
 		return TFREC_AMD_E_INVAL;
 	*n = 0;
-	if (!c->groups.empty()) {
-		int rc = TFREC_AMD_OK;
-		for (auto *in : c->groups) {
-			int k = 0;
-			const int r = tfrec_amd_pending_events(in, &k);
-			if (r != TFREC_AMD_OK && r != TFREC_AMD_E_OVERFLOW)
-				return r;
-			rc = r == TFREC_AMD_E_OVERFLOW ? r : rc;
-			*n += k;
-		}
-		return rc;
-	}
 	if (c->poisoned) {  // (copied[head] may never have been recorded: synchronising on it would succeed at once)
 		snprintf(g_err, sizeof(g_err), "an earlier submit failed half way: the context must be recreated");
 		return TFREC_AMD_E_STATE;
@@ -1246,22 +1081,6 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 	if (!c || !n_out || cap < 0 || (cap > 0 && !out))
 		return TFREC_AMD_E_INVAL;
 	*n_out = 0;
-	if (!c->groups.empty()) {
-		// the groups hold consecutive streams and each drain orders by (stream, slot, seq): one after the other IS the order
-		int rc = TFREC_AMD_OK, total = 0;
-		for (auto *in : c->groups) {
-			int k = 0;
-			const int r = tfrec_amd_drain_events(in, out ? out + total : nullptr, cap - total, &k);
-			if (r != TFREC_AMD_OK && r != TFREC_AMD_E_OVERFLOW)
-				return r;
-			rc = r == TFREC_AMD_E_OVERFLOW ? r : rc;
-			for (int i = 0; i < k; i++)
-				out[total + i].stream += (uint32_t)in->stream_base;
-			total += k;
-		}
-		*n_out = total;
-		return rc;
-	}
 	if (c->poisoned) {
 		snprintf(g_err, sizeof(g_err), "an earlier submit failed half way: the context must be recreated");
 		return TFREC_AMD_E_STATE;
@@ -1350,11 +1169,6 @@ int tfrec_amd_drain_events(tfrec_amd_ctx *c, tfrec_amd_event *out, int cap, int 
 
 int tfrec_amd_read_stage0(tfrec_amd_ctx *c, int stream, int16_t *out, size_t n_pairs)
 {
-	if (c && !c->groups.empty()) {
-		int local = 0;
-		tfrec_amd_ctx *in = group_of(c, stream, &local);
-		return in ? tfrec_amd_read_stage0(in, local, out, n_pairs) : TFREC_AMD_E_INVAL;
-	}
 	if (!c || !out || !c->in10x || stream < 0 || stream >= c->cfg.n_streams ||
 	    n_pairs > (size_t)c->last_blocks * 4 * kBlockDec)
 		return TFREC_AMD_E_INVAL;
@@ -1368,11 +1182,6 @@ int tfrec_amd_read_stage0(tfrec_amd_ctx *c, int stream, int16_t *out, size_t n_p
 
 int tfrec_amd_read_decimated(tfrec_amd_ctx *c, int stream, int16_t *out, size_t n_pairs)
 {
-	if (c && !c->groups.empty()) {
-		int local = 0;
-		tfrec_amd_ctx *in = group_of(c, stream, &local);
-		return in ? tfrec_amd_read_decimated(in, local, out, n_pairs) : TFREC_AMD_E_INVAL;
-	}
 	if (!c || !out || stream < 0 || stream >= c->cfg.n_streams || n_pairs > (size_t)c->last_blocks * kBlockDec)
 		return TFREC_AMD_E_INVAL;
 	int rc = tfrec_amd_sync(c);
@@ -1385,17 +1194,6 @@ int tfrec_amd_read_decimated(tfrec_amd_ctx *c, int stream, int16_t *out, size_t 
 
 int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 {
-	if (c && n && !c->groups.empty()) {
-		*n = 0;
-		for (auto *in : c->groups) {
-			uint64_t k = 0;
-			const int rc = tfrec_amd_atan_uncertain(in, &k);
-			if (rc != TFREC_AMD_OK)
-				return rc;
-			*n += k;
-		}
-		return TFREC_AMD_OK;
-	}
 	if (!c || !n)
 		return TFREC_AMD_E_INVAL;
 	if (c->poisoned)
@@ -1414,20 +1212,6 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *c, uint64_t *n)
 
 int tfrec_amd_get_fm_stats(tfrec_amd_ctx *c, tfrec_amd_fm_stats *out)
 {
-	if (c && out && !c->groups.empty()) {
-		memset(out, 0, sizeof(*out));
-		for (auto *in : c->groups) {
-			tfrec_amd_fm_stats k;
-			const int rc = tfrec_amd_get_fm_stats(in, &k);
-			if (rc != TFREC_AMD_OK)
-				return rc;
-			out->resolved += k.resolved;
-			out->host_verified += k.host_verified;
-			out->host_mismatch += k.host_mismatch;
-			out->undecidable += k.undecidable;
-		}
-		return TFREC_AMD_OK;
-	}
 	if (!c || !out)
 		return TFREC_AMD_E_INVAL;
 	if (c->poisoned)
@@ -1484,11 +1268,6 @@ int tfrec_amd_fm_dev_probe(int device, int kind, const void *quads_v, size_t n, 
 
 int tfrec_amd_read_thresh(tfrec_amd_ctx *c, int stream, int *thresh)
 {
-	if (c && !c->groups.empty()) {
-		int local = 0;
-		tfrec_amd_ctx *in = group_of(c, stream, &local);
-		return in ? tfrec_amd_read_thresh(in, local, thresh) : TFREC_AMD_E_INVAL;
-	}
 	if (!c || !thresh || stream < 0 || stream >= c->cfg.n_streams)
 		return TFREC_AMD_E_INVAL;
 	if (!c->d_fsk) {
@@ -1506,25 +1285,6 @@ int tfrec_amd_read_thresh(tfrec_amd_ctx *c, int stream, int *thresh)
 
 int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 {
-	if (c && out && !c->groups.empty()) {
-		// a kernel's time per batch = the sum over the groups' launches of it (they run one after the other on one stream);
-		// the spans (front end, chains, total) = from the first group's start to the last group's end is not recorded:
-		// the longest group's span stands for them
-		memset(out, 0, sizeof(*out));
-		for (auto *in : c->groups) {
-			tfrec_amd_timings k;
-			const int rc = tfrec_amd_get_timings(in, &k);
-			if (rc != TFREC_AMD_OK)
-				return rc;
-			const float *src = reinterpret_cast<const float *>(&k);
-			float *dst = reinterpret_cast<float *>(out);
-			for (size_t i = 0; i < sizeof(k) / sizeof(float); i++)
-				dst[i] += src[i];
-			out->chains_ms = std::max(out->chains_ms - k.chains_ms, k.chains_ms);
-			out->total_ms = std::max(out->total_ms - k.total_ms, k.total_ms);
-		}
-		return TFREC_AMD_OK;
-	}
 	if (!c || !out)
 		return TFREC_AMD_E_INVAL;
 	if (!c->timed)
@@ -1606,8 +1366,6 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 
 int tfrec_amd_get_layout(tfrec_amd_ctx *c, int *n_streams)
 {
-	if (c && !c->groups.empty())
-		return tfrec_amd_get_layout(c->groups[0], n_streams);
 	if (!c || !n_streams)
 		return TFREC_AMD_E_INVAL;
 	*n_streams = (c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS) ? 2 : (c->deep ? 6 : 4);
@@ -1616,18 +1374,6 @@ int tfrec_amd_get_layout(tfrec_amd_ctx *c, int *n_streams)
 
 int tfrec_amd_get_memory(tfrec_amd_ctx *c, uint64_t *device_bytes, uint64_t *pinned_host_bytes)
 {
-	if (c && device_bytes && pinned_host_bytes && !c->groups.empty()) {
-		*device_bytes = *pinned_host_bytes = 0;
-		for (auto *in : c->groups) {
-			uint64_t d = 0, h = 0;
-			const int rc = tfrec_amd_get_memory(in, &d, &h);
-			if (rc != TFREC_AMD_OK)
-				return rc;
-			*device_bytes += d;
-			*pinned_host_bytes += h;
-		}
-		return TFREC_AMD_OK;
-	}
 	if (!c || !device_bytes || !pinned_host_bytes)
 		return TFREC_AMD_E_INVAL;
 	*device_bytes = c->dev_bytes;
@@ -1639,18 +1385,6 @@ int tfrec_amd_get_memory(tfrec_amd_ctx *c, uint64_t *device_bytes, uint64_t *pin
 
 int tfrec_amd_get_stats(tfrec_amd_ctx *c, tfrec_amd_stats *out)
 {
-	if (c && out && !c->groups.empty()) {
-		memset(out, 0, sizeof(*out));
-		for (auto *in : c->groups) {
-			tfrec_amd_stats k;
-			const int rc = tfrec_amd_get_stats(in, &k);
-			if (rc != TFREC_AMD_OK)
-				return rc;
-			for (int i = 0; i < 8; i++)
-				reinterpret_cast<uint64_t *>(out)[i] += reinterpret_cast<const uint64_t *>(&k)[i];
-		}
-		return TFREC_AMD_OK;
-	}
 	if (!c || !out)
 		return TFREC_AMD_E_INVAL;
 	memset(out, 0, sizeof(*out));

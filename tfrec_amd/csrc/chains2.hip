@@ -636,20 +636,6 @@ __device__ __forceinline__ BiquadEnd end_of(const Biquad &f)
 // Two slot buffers per lane: slot k (A) is filtered while slot k+1 (B) is in flight; then B moves to A and slot k+2 is
 // requested.  (A third buffer -- two slots in flight throughout -- made the pass faster alone and the batch slower: 30-50
 // more registers per lane)
-// MODE 3 (round 5, the default): K3a and K3b in ONE launch.  The repair run of segment k needs the end state of segment
-// k-1's speculative run and the checkpoints of segment k's: a lane that finishes a speculative run counts it at the
-// segment's two boundaries (T.segcnt, zeroed per submit), and whoever brings a boundary's count to two -- the second of
-// its two neighbours to finish -- runs that segment's repair next, before it takes another speculative segment from the
-// queue.  No lane ever waits for another.  What a repair run reads of another lane's results (the end state, the
-// checkpoints) was written before that lane's fence + count and is read past the vector L1 (agent-scope loads).  As two
-// launches the repair pass could not start before the LAST speculative segment had ended, and each pass ended with its
-// slowest lane: the TFA_2-family biquad stream (speculate 2.2 ms + repair 2.8 ms inside the batch) was one of the serial
-// loops that set the batch period.
-__device__ __forceinline__ double load_agent_f64(const double *p)
-{
-	return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
 template <bool WHB, int MODE>
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
@@ -659,23 +645,21 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 #ifdef TFREC_AMD_SPEC_PRIO
 	__builtin_amdgcn_s_setprio(TFREC_AMD_SPEC_PRIO);
 #endif
-	constexpr bool FUSED = MODE == 3;
+	constexpr bool REPAIR = MODE != 0;
+#ifdef TFREC_AMD_SPEC_CLAIM  // (sensitivity experiment, see slicer_kernel)
+	asm volatile("" ::: TFREC_AMD_SPEC_CLAIM);
+#endif
 	extern __shared__ __attribute__((aligned(16))) uint8_t k3_tile[];  // K3Tile<WHB>::kSize bytes
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	constexpr int q = 4 + 2 * (WHB ? 1 : 0);
 	const uint32_t qcount = T.queue[q].count;
-	uint32_t *head = (MODE == 0 || FUSED) ? &T.queue[q].head : (MODE == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
+	uint32_t *head = MODE == 0 ? &T.queue[q].head : (MODE == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
 	const bool worker = (int)threadIdx.x < lanes;  // the other lanes only help to store
 	bool busy = false, dry = !worker;
-	bool rep = MODE == 1 || MODE == 2;  // the lane's current run is a repair run (FUSED: per run)
-	// FUSED: repairs this lane owes (segment indices sk): at most two, one per boundary of the speculative segment it finished
-	size_t owe0 = 0, owe1 = 0;
-	int nowe = 0;
 	// the lane's segment
 	int c = 0, count = 0, nslots = 0, min_slots = 0, done = 0, nsamples = 0, loaded = 0;
 	size_t sk = 0;
-	int kseg = 0;
 	const void *in = nullptr;
 	void *out = nullptr;
 	double2 *ckrow = nullptr;
@@ -692,111 +676,76 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 	auto fetch = [&](K3Chunk<WHB> &buf, double2 &ck) {
 		if (loaded < nslots) {
 			k3_load<WHB>(buf, in, pl.w.og + kChunk * pl.i, prev0);
-			if (rep && ck_slot(pl.w.slot0 + pl.i)) {
-				if (FUSED) {  // (written by another lane of this launch)
-					ck.x = load_agent_f64(&ckrow[pl.w.slot0 + pl.i].x);
-					ck.y = load_agent_f64(&ckrow[pl.w.slot0 + pl.i].y);
-				} else {
-					ck = ckrow[pl.w.slot0 + pl.i];
-				}
-			}
+			if (REPAIR && ck_slot(pl.w.slot0 + pl.i))
+				ck = ckrow[pl.w.slot0 + pl.i];
 			loaded++;
 			if (loaded < nslots)
 				seg_advance(pl, T, c, M, count);
 		}
-	};
-	// set the lane up for segment k of chain c_; false: nothing to run
-	auto begin_segment = [&](int c_, int k) -> bool {
-		c = c_;
-		kseg = k;
-		const int a = c / n_streams, s = c - a * n_streams;
-		sk = (size_t)c * T.segcap + k;
-		const int left = T.vtotal[c] - k * kSegSlots;
-		nslots = left < kSegSlots ? left : kSegSlots;
-		if (nslots <= 0)
-			return false;
-		const uint2 start = T.segstart[sk];
-		count = T.count[c];
-		cf = L.params[a].iir;
-		in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
-		out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)(c - T.ld_c0) * T.slots * 32);
-		ckrow = T.ckpt + (size_t)(c - T.ck_c0) * T.slots;
-		prev0 = T.prevdec[s];  // not the chain state's prev_i/q: stage B of the previous submit may still be running
-		pp.j = (int)start.x;
-		pp.i = (int)start.y;
-		pp.w = seg_win(T, c, pp.j, M);
-		pl = pp;
-		done = nsamples = loaded = 0;
-		fetch(A, ckA);
-		fetch(B, ckB);
-		return true;
 	};
 	while (true) {
 		// ---- take segments
 		const unsigned long long idle = __ballot(!busy && !dry), running = __ballot(busy);
 		if (idle != 0ull && (running == 0ull || __builtin_popcountll(idle) >= 16)) {
 			while (!busy && !dry) {  // (a segment with nothing to run is finished on the spot)
-				if (FUSED && nowe > 0) {  // a repair this lane owes: segment owe0 from the speculative end of the segment before it
-					const size_t rsk = owe0;
-					owe0 = owe1;
-					nowe--;
-					const int c_ = (int)(rsk / (size_t)T.segcap), k = (int)(rsk - (size_t)c_ * T.segcap);
-					rep = true;
-					min_slots = 0;
-					const BiquadEnd *e = &T.segend1[rsk - 1];
-					f.dn1 = load_agent_f64(&e->dn1);
-					f.dn2 = load_agent_f64(&e->dn2);
-					f.yn = load_agent_f64(&e->yn);
-					f.yn1 = load_agent_f64(&e->yn1);
-					if (begin_segment(c_, k))
-						busy = true;
-					else
-						T.segfix[rsk] = 0;
-					continue;
-				}
 				const uint32_t idx = atomicAdd(head, 1u);
 				if (idx >= qcount) {
 					dry = true;
 					break;
 				}
 				const uint2 it = T.items[(size_t)q * total + idx];
-				const int c_ = (int)it.x;
+				c = (int)it.x;
 				const int k = (int)it.y;
-				const int a = c_ / n_streams, s = c_ - a * n_streams;
-				const size_t sk_ = (size_t)c_ * T.segcap + k;
+				const int a = c / n_streams, s = c - a * n_streams;
+				sk = (size_t)c * T.segcap + k;
 				bool run = true;
 				f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
 				min_slots = 0;
-				if (MODE == 0 || FUSED) {
-					rep = false;
+				if (MODE == 0) {
 					if (k == 0)
 						f = L.states[a][s].iir;  // the chain's first segment starts from the true carried state
 				} else if (MODE == 1) {
 					run = k > 0;
 					if (run)
-						f = biquad_of(T.segend1[sk_ - 1]);
+						f = biquad_of(T.segend1[sk - 1]);
 				} else {
 					// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
 					// the true one, its end state segend2[k-1] is where segment k really starts
-					run = k > 1 && !(T.segfix[sk_ - 1] & kSegConverged);
+					run = k > 1 && !(T.segfix[sk - 1] & kSegConverged);
 					if (run) {
-						f = biquad_of(T.segend2[sk_ - 1]);
-						min_slots = T.segfix[sk_] & ~kSegConverged;
+						f = biquad_of(T.segend2[sk - 1]);
+						min_slots = T.segfix[sk] & ~kSegConverged;
 					} else {
-						T.segfix2[sk_] = 0;
+						T.segfix2[sk] = 0;
 					}
 				}
 				if (!run)
 					continue;
-				if (!begin_segment(c_, k)) {  // (cannot happen: the queue holds existing segments)
-					if (MODE == 0 || FUSED)
-						T.segend1[sk_] = end_of(f);
+				const int left = T.vtotal[c] - k * kSegSlots;
+				nslots = left < kSegSlots ? left : kSegSlots;
+				if (nslots <= 0) {  // (cannot happen: the queue holds existing segments)
+					if (MODE == 0)
+						T.segend1[sk] = end_of(f);
 					else if (MODE == 1)
-						T.segfix[sk_] = 0;
+						T.segfix[sk] = 0;
 					else
-						T.segfix2[sk_] = kSegRan;
+						T.segfix2[sk] = kSegRan;
 					continue;
 				}
+				const uint2 start = T.segstart[sk];
+				count = T.count[c];
+				cf = L.params[a].iir;
+				in = WHB ? (const void *)(dec + (size_t)s * dec_stride) : (const void *)(fmdev + (size_t)s * fmdev_stride);
+				out = WHB ? (void *)(dev32 + (size_t)s * T.slots * 32) : (void *)(ld16 + (size_t)(c - T.ld_c0) * T.slots * 32);
+				ckrow = T.ckpt + (size_t)(c - T.ck_c0) * T.slots;
+				prev0 = T.prevdec[s];  // not the chain state's prev_i/q: stage B of the previous submit may still be running
+				pp.j = (int)start.x;
+				pp.i = (int)start.y;
+				pp.w = seg_win(T, c, pp.j, M);
+				pl = pp;
+				done = nsamples = loaded = 0;
+				fetch(A, ckA);
+				fetch(B, ckB);
 				busy = true;
 			}
 		}
@@ -807,7 +756,6 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 		}
 		// ---- one slot
 		void *dst = nullptr;
-		bool publish = false;  // FUSED: this iteration ended a speculative run
 		if (busy) {
 			const int nv = pp.w.n - kChunk * pp.i < kChunk ? pp.w.n - kChunk * pp.i : kChunk;
 			uint4 *row = reinterpret_cast<uint4 *>(k3_tile_row<WHB>(k3_tile));  // (the transposed reads of the last slot were issued before)
@@ -824,7 +772,7 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 			done++;
 			bool conv = false;
 			const bool at_ck = ck_slot(pp.w.slot0 + pp.i);
-			if (!rep) {
+			if (!REPAIR) {
 				if (at_ck)
 					ckrow[pp.w.slot0 + pp.i] = make_double2(f.yn, f.yn1);
 			} else {  // the state equals the speculative checkpoint bit for bit (the two last inputs are then shared too):
@@ -833,10 +781,9 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 			}
 			if (conv || done >= nslots) {
 				busy = false;
-				if (!rep) {
+				if (MODE == 0) {
 					T.segend1[sk] = end_of(f);
-					publish = FUSED;
-				} else if (MODE == 1 || FUSED) {
+				} else if (MODE == 1) {
 					T.segfix[sk] = done | (conv ? kSegConverged : 0);
 #ifndef TFREC_AMD_PROFILE_WHB  // (that build counts the WHB demodulator's cycles in this slot)
 					atomicAdd(&T.stats[5], (unsigned long long)done);
@@ -858,24 +805,6 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 			}
 		}
 		k3_store_t<WHB>(k3_tile, dst);
-		if (FUSED && publish) {
-			// this run's results (outputs, checkpoints, end state: all stored by now), then its count at the segment's two
-			// boundaries: the second neighbour to arrive at a boundary owes the repair of the segment behind it
-			__threadfence();
-			if (kseg > 0 && atomicAdd(&T.segcnt[sk], 1) == 1) {
-				owe0 = sk;
-				nowe = 1;
-			}
-			if (kseg + 1 < (T.vtotal[c] + kSegSlots - 1) / kSegSlots && atomicAdd(&T.segcnt[sk + 1], 1) == 1) {
-				if (nowe == 0)
-					owe0 = sk + 1;
-				else
-					owe1 = sk + 1;
-				nowe++;
-			}
-			if (nowe > 0)
-				__threadfence();
-		}
 	}
 }
 
@@ -1343,6 +1272,9 @@ __global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void slicer_kernel(const ui
 	// front end beside them needs 16.6 KB per workgroup of what the CU's 160 KB have left
 	extern __shared__ uint4 slot_lds[];
 	latency_prio();
+#ifdef TFREC_AMD_SLICER_CLAIM  // (sensitivity experiment: -DTFREC_AMD_SLICER_CLAIM='"v175"' makes the kernel hold that many registers)
+	asm volatile("" ::: TFREC_AMD_SLICER_CLAIM);
+#endif
 	uint4 *my_lds = slot_lds + threadIdx.x;
 	if ((int)threadIdx.x >= lanes)
 		return;
@@ -3520,15 +3452,16 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// The repair passes run ~35 slots per segment on average, and the whole segment (116) for the few whose trajectories
 	// never meet: with a lane per segment a wave is as slow as its slowest lane and two thirds of its lanes idle.
 	// Several segments per lane instead (the flat loop of spec_biquad_kernel hands a lane the next one): a
-	// twelfth of the waves (3-4 segments per lane at 1024 streams); at least 256 so that small batches keep their parallelism.
-	static const int repair_div = env_int("TFREC_AMD_REPAIR_DIV", 8, 1, 64);  // (x kSegSlots / 128: the wave count of round 4's 12 at 128-slot segments ... measured 6-8)
+	// eighth of the waves; at least 256 so that small batches keep their parallelism.
+	static const int repair_div = env_int("TFREC_AMD_REPAIR_DIV", 8, 1, 64);  // (256-slot segments: 6-8 measured equal; round 4 had 12 at 128 slots)
 	const int repair_blocks = std::min(seg_blocks, std::max(256, seg_blocks / repair_div));
-	// The speculative pass with an eighth of the worst-case waves (~1000 at 1024 streams: 2-3 segments per lane).  A lane
+	// The speculative pass with a fifth of the worst-case waves (~830 at 1024 streams: 1-2 segments of 256 slots per lane).  A lane
 	// reads 64 (+4) bytes per slot at an arbitrary 2-byte offset of its row, so consecutive slots share a 128-byte line;
 	// with a lane per segment the lines in flight (2540 waves x 64 lanes x 2 lines = 40 MB) never survived in the 32 MB
 	// of L2 until the lane came back: the pass fetched 2.9 GB for 1.1 GB of input.  With ~1000 waves: 1.4 GB, and the
 	// batch 2 % shorter.  (A sixteenth starves the WHB chain.)
-	static const int spec_div = env_int("TFREC_AMD_SPEC_DIV", 5, 1, 64);  // (256-slot segments: 4-6 measured equal, 3 worse)
+	static const size_t lds_pad_spec = (size_t)env_int("TFREC_AMD_LDS_PAD_SPEC", 0, 0, 48 << 10);
+	static const int spec_div = env_int("TFREC_AMD_SPEC_DIV", 5, 1, 64);  // (256-slot segments: 4-6 measured equal, 3 and 8 worse; round 4 had 8 at 128 slots)
 	const int spec_blocks = std::min(seg_blocks, std::max(256, seg_blocks / spec_div));
 	// (few chains: the lanes of the lane-per-window kernels are mostly idle anyway and latency is all that counts)
 	static const int long_window_env = env_int("TFREC_AMD_COOP_MIN", 0, 0);
@@ -3550,14 +3483,6 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	if (P.ws != P.fs)
 		TRY(hipStreamWaitEvent(P.ws, P.ev_front, 0));
 	TRY(hipMemsetAsync(T.queue, 0, (kNQueues + 1) * sizeof(WorkQueue), P.ws));
-	// TFREC_AMD_FUSED_BIQUAD=0: speculative and first repair pass as two launches (round 4); 1 (default): one launch (MODE 3)
-	static const int fused_biquad = env_int("TFREC_AMD_FUSED_BIQUAD", 1, 0, 1);
-	// TFREC_AMD_REPAIR2=0: no second parallel repair pass (the chain walk repairs what the first left, serially)
-	static const int repair2 = env_int("TFREC_AMD_REPAIR2", 1, 0, 1);
-	if (fused_biquad && T.segcnt_bytes)
-		TRY(hipMemsetAsync(T.segcnt, 0, T.segcnt_bytes, P.ws));
-	if (!repair2 && T.segcnt_bytes)  // (fix_chain reads "the second repair did not run" for every segment)
-		TRY(hipMemsetAsync(T.segfix2, 0, T.segcnt_bytes, P.ws));
 	mark(0, P.ws);
 	hipLaunchKernelGGL(windows_kernel, dim3(n_streams), block, 0, P.ws, mask, mask_stride, n_streams, n_blocks, L, T,
 			   long_window);
@@ -3583,24 +3508,16 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipEventRecord(P.ev_fm, P.kw));
 		}
 		mark(9, P.kw);
-		if (fused_biquad) {
-			if (!(skip & 256))
-			hipLaunchKernelGGL((spec_biquad_kernel<true, 3>), dim3(spec_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
-					   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-			mark(10, P.kw);
-		} else {
-			if (!(skip & 256))
-			hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(spec_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
-					   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-			mark(10, P.kw);
-			if (!(skip & 256))
-			hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
-					   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		}
-		if (repair2 && !(skip & 256))
-		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(repair_blocks), block, K3Tile<true>::kSize, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+		if (!(skip & 256))
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 0>), dim3(spec_blocks), block, K3Tile<true>::kSize + lds_pad_spec, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-
+		mark(10, P.kw);
+		if (!(skip & 256))
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 1>), dim3(repair_blocks), block, K3Tile<true>::kSize + lds_pad_spec, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
+		if (!(skip & 256))
+		hipLaunchKernelGGL((spec_biquad_kernel<true, 2>), dim3(repair_blocks), block, K3Tile<true>::kSize + lds_pad_spec, P.kw, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(11, P.kw);
 		hipLaunchKernelGGL(fix_biquad_kernel, dim3(n_streams, L.n_active), block, 0, P.kw, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, 2);
@@ -3659,21 +3576,17 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 64));
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
-		const bool mark_own = kind == 0 && P.mz != nullptr;
-		if (mark_own) {  // the peak pieces of the long windows beside the short windows' slicers (they meet before coop_slicer_kernel)
-			(void)hipEventRecord(P.ev_t1go, s_);
-			(void)hipStreamWaitEvent(P.mz, P.ev_t1go, 0);
-			hipLaunchKernelGGL(mark_kernel, dim3(std::max(1, win_blocks / 16)), dim3(256), 0, P.mz, dec, dec_stride, n_streams,
-					   n_blocks, L, T);
-			(void)hipEventRecord(P.ev_mark, P.mz);
-		} else if (kind == 0)
+		if (kind == 0)
 			if (!(skip & 8))
 			hipLaunchKernelGGL(mark_kernel, dim3(std::max(1, win_blocks / 16)), dim3(256), 0, s_, dec, dec_stride, n_streams,
 					   n_blocks, L, T);
 		// The lanes take their windows from a queue, so the wave count is a free parameter: fewer waves = fewer registers
 		// held for milliseconds by a latency-bound kernel (the front end beside it lives on what is left), more windows per lane
 		static const int slicer_div = env_int("TFREC_AMD_SLICER_DIV", 1, 1, 64);
-		const size_t slds = (kind == 0 ? 8 : 4) * 64 * sizeof(uint4);
+		// (TFREC_AMD_LDS_PAD_SLICER / _SPEC: sensitivity experiments -- extra dynamic LDS bytes per workgroup of the lane-per-window
+		// slicers / the biquad passes: how much of the period is these kernels' LDS footprint beside the front end's 16.6 KB tiles)
+		static const size_t lds_pad_slicer = (size_t)env_int("TFREC_AMD_LDS_PAD_SLICER", 0, 0, 48 << 10);
+		const size_t slds = (kind == 0 ? 8 : 4) * 64 * sizeof(uint4) + lds_pad_slicer;
 		const bool split = kind == 1 && P.cz != nullptr;
 		if (split) {
 			// the long windows' heads first (few windows: a small grid), then -- beside each other -- their tails on cz and
@@ -3697,8 +3610,6 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			hipLaunchKernelGGL(slicer_kernel, dim3(std::max(64, win_blocks / slicer_div)), block, slds, s_, dec, dec_stride, ld16, n_streams, n_blocks, L, T,
 					   lanes_win, head_chunks, kind, 0);
 			mark(m0 + 1, s_);
-			if (mark_own)
-				(void)hipStreamWaitEvent(s_, P.ev_mark, 0);
 			if (!(skip & (kind == 0 ? 2 : 1)))
 			hipLaunchKernelGGL(coop_slicer_kernel, dim3(coop_blocks), block, 0, s_, dec, dec_stride, ld16, n_streams, n_blocks, L,
 					   T, kind);
@@ -3736,14 +3647,9 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			mark(25, P.k2);
 		}
 		mark(1, P.k2);
-		if (!(skip & 128)) {
-			if (fused_biquad)
-				hipLaunchKernelGGL((spec_biquad_kernel<false, 3>), dim3(spec_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
-						   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-			else
-				hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
-						   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		}
+		if (!(skip & 128))
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize + lds_pad_spec, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(2, P.k2);
 		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
 			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
@@ -3752,11 +3658,11 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}
-		if (!(skip & 128) && !fused_biquad)
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 1>), dim3(repair_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+		if (!(skip & 128))
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 1>), dim3(repair_blocks), block, K3Tile<false>::kSize + lds_pad_spec, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		if (!(skip & 128) && repair2)
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(repair_blocks), block, K3Tile<false>::kSize, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+		if (!(skip & 128))
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 2>), dim3(repair_blocks), block, K3Tile<false>::kSize + lds_pad_spec, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(3, P.k2);
 		hipLaunchKernelGGL(fix_biquad_kernel, dim3(n_streams, L.n_active), block, 0, P.k2, dec, dec_stride, fmdev, fmdev_stride,

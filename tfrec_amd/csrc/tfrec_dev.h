@@ -241,9 +241,6 @@ struct WinTables {
 	int32_t *segfix;        // [chains*segcap] repair run: slots rewritten | kSegConverged
 	BiquadEnd *segend3;     // [chains*segcap] ... second repair run (started from segend2 of the segment before)
 	int32_t *segfix2;       // [chains*segcap] second repair run: slots rewritten | kSegConverged | kSegRan (0: not run)
-	size_t segcnt_bytes;
-	int32_t *segcnt;        // [chains*segcap] fused speculate + repair launch: speculative runs finished at the boundary in front of
-	                        // the segment (0..2), zeroed per submit
 	int32_t *overflow;      // set when a chain found more than cap windows
 	unsigned long long *stats;  // [8] tfrec_amd_stats
 	const uint32_t *prevdec;  // [n_streams] the decimated sample before this submit's first one (front end)
@@ -296,8 +293,6 @@ struct PipeCtl {
 	// TFA_2 family, stage B split: once the long windows' heads are sliced (cs), the cooperative slicers of their tails
 	// run on cz beside the short windows' slicers on cs (nullptr: one after the other on cs)
 	hipStream_t cz;
-	hipStream_t mz;            // the TFA_1 peak pieces (mark_kernel) beside the short windows' slicers on t1 (TFREC_AMD_MARK_OWN), or nullptr
-	hipEvent_t ev_mark, ev_t1go;
 	hipStream_t fq;            // the discriminator pass's own stream (TFREC_AMD_FMDEV_OWN), or nullptr: at the head of k2
 	hipEvent_t ev_heads, ev_coop;
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
