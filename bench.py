@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short secondary measurements of BASELINE configs[1] and configs[4] (N=1 only)")
     ap.add_argument("--depth", type=int, default=4, help="batches kept in the submit/drain FIFO (1..4)")
+    ap.add_argument("--bg-traffic-gb", type=float, default=0.0,
+                    help="EXPERIMENT (what binds?): beside every batch, a device-to-device copy of this many GB of HBM traffic (half read, "
+                         "half written, coalesced) on a stream of its own; the line then carries config.bg_traffic_gb and is not a result")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
                          "(secondary measurement; the default line stays config 2)")
@@ -327,6 +330,11 @@ def main():
     # of consecutive batches overlap.  Exactly n_steps batches are submitted and drained inside run().
     depth = max(1, min(a.depth, api.FIFO_DEPTH))
 
+    bg = None
+    if a.bg_traffic_gb > 0:
+        n_bg = int(a.bg_traffic_gb * 1e9 / 2)
+        bg = (torch.empty(n_bg, dtype=torch.uint8, device=dev), torch.empty(n_bg, dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev))
+
     def run(n_steps, collect, src=None, stamps=None):
         n_ev = 0
         queued = 0
@@ -334,6 +342,9 @@ def main():
             while queued < n_steps and queued - k < depth:
                 r.submit(d_iq if src is None else src)
                 queued += 1
+                if bg is not None:
+                    with torch.cuda.stream(bg[2]):
+                        bg[1].copy_(bg[0], non_blocking=True)
             n_ev += len(r.drain())
             if stamps is not None:
                 stamps.append(time.perf_counter())
@@ -668,6 +679,7 @@ def main():
                 "atan_host_mismatch": fm_bad, "atan_undecidable": fm["undecidable"],
                 # slow-path decisions beyond the per-submit log (62): exact by construction, but not compared with this host's libm
                 "atan_unverified": fm["resolved"] - fm["host_verified"],
+                "bg_traffic_gb": a.bg_traffic_gb if a.bg_traffic_gb > 0 else None,
                 "dist_backend": a.dist_backend if world > 1 else None,
                 "rank_input_crc32": input_crc, "events_all_ranks": events_all,
             },
