@@ -150,7 +150,7 @@ def cpu_baseline(iq_sample: np.ndarray, types: int, thresh: int, budget_s: float
 # (TFREC_AMD_DEBUG_WINHIST=1: profiles/r04_winhist.txt); bits, decoders and CRCs are per telegram: negligible.
 ALG_OPS = {"front": 12.25, "fm_dev": 34.0, "tfa2_chain": 19.0, "tfa1": 10.0, "whb": 28.0}
 ALG_DUTY = {"tfa1": 0.457, "tfa2": 0.455, "tfa3": 0.469, "tx22": 0.472, "whb": 0.463}  # profiles/r04_winhist.txt
-SIMDS, CLOCK_GHZ = 1024, 2.4
+SIMDS, CLOCK_GHZ = 1024, 2.36  # (measured under load: profiles/r05_clocks_power.txt)
 
 
 def algorithmic_floor_ms(n_streams: int, n_blocks: int, types: int) -> dict:
@@ -409,7 +409,7 @@ def main():
     step_ms = np.diff(np.array(stamps)) * 1e3  # time between consecutive drains of this rank
     events_all = shard.sum_over_ranks(n_events, red_dev)
 
-    # ---- the discriminator's self check over everything this context processed (DESIGN.md 4.8): samples decided by the
+    # ---- the discriminator's self check over everything this context processed (DESIGN.md section 4, item 8): samples decided by the
     # exact slow path, and how many of the logged decisions differ from this host's libm (the reference's arithmetic)
     fm = r.fm_stats()
     fm_bad = shard.sum_over_ranks(fm["host_mismatch"], red_dev)

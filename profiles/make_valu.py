@@ -22,7 +22,7 @@ so "1.4-2.6 cycles per instruction" and a roof of 1.79 ms were a factor two too 
 """
 import json, re, sys
 
-CLOCK_GHZ = 2.4
+CLOCK_GHZ = 2.36  # measured under the pipeline's load (profiles/r05_clocks_power.txt, r05_device_activity.txt); rounds 1-4 assumed 2.4
 N_SIMD = 1024
 
 

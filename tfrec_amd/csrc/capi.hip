@@ -890,7 +890,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		(void)hipDeviceSynchronize();
 		unsigned long long st[16] = { 0 };
 		(void)hipMemcpy(st, c->win[set].stats, sizeof(st), hipMemcpyDeviceToHost);
-		fprintf(stderr, "COOPSTAT (one submit) TFA_2 family: frozen one-block steps %llu, accepted %llu, rejected %llu, other frozen steps %llu; TFA_1: steps %llu, candidate runs %llu\n", st[7], st[8], st[9], st[10], st[11], st[12]);
+		fprintf(stderr, "COOPSTAT (one submit) TFA_2 family: frozen one-block steps %llu, accepted %llu, rejected %llu, other frozen steps %llu; TFA_1: steps %llu, candidate runs %llu; TFA_2 walked steps with a full mask %llu, candidates in walked steps %llu, walked steps that begin inside a run %llu\n", st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
 	}
 #endif
 	if (getenv("TFREC_AMD_DEBUG_WINHIST") && c->submit_seq == 3) {  // (debug: the window length distribution of one submit)

@@ -27,7 +27,7 @@
 //                          lane-parallel scan (speculated), every decision recorded;
 //   K4v whb_verify_kernel  the reference's own recurrence over those samples, four streams per wave, compares the
 //                          decisions and carries the exact filter state; failed streams are redone by
-//                          whb_demod_kernel<true, true> (the exact form), their events retracted (DESIGN.md 4.7b).
+//                          whb_demod_kernel<true, true> (the exact form), their events retracted (DESIGN.md section 4, item 7).
 //   K5  decode_kernel      lane per window: the decoders (store_bit) over the window's packed bits;
 //       commit_kernel      lane per (stream, slot): walks the windows in order: checks the tfa2 speculation (a chain
 //                          with a window to re-run goes to commit_wave_kernel, wave per chain), overlays the windows'
@@ -60,7 +60,7 @@ constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
 __device__ __forceinline__ int tfa1_decay(int m) { return m - (int)(((uint32_t)m + 19u) / 20u); }
 
 // Wave priority of the LATENCY-bound kernels (serial chains per lane or per wave: slicers, WHB stage 2 and its check):
-// experiment knob, see DESIGN.md 7d
+// experiment knob, see profiles/NOTES.md (round 3)
 #ifndef TFREC_AMD_LAT_PRIO
 #define TFREC_AMD_LAT_PRIO 0
 #endif
@@ -583,7 +583,7 @@ __device__ __forceinline__ bool same_bits(double a, double b) { return __double_
 // Checkpoints of the speculative pass are kept for every kCkEvery-th slot (by slot number, so every pass agrees on
 // which): a repair run can only join the speculative trajectory there, up to kCkEvery - 1 slots later than with a
 // checkpoint per slot (~35 slots per run on average), for a quarter of the 16-byte lane-per-row checkpoint stores and
-// loads -- partial-line accesses, the expensive kind (section 7c).
+// loads -- partial-line accesses, the expensive kind (profiles/NOTES.md, round 2).
 #ifndef TFREC_AMD_CK_EVERY
 #define TFREC_AMD_CK_EVERY 4
 #endif
@@ -635,7 +635,7 @@ __device__ __forceinline__ BiquadEnd end_of(const Biquad &f)
 // table reads during which the wave stalls, so idle lanes wait until a quarter of the wave is idle (or nothing runs).
 // Two slot buffers per lane: slot k (A) is filtered while slot k+1 (B) is in flight; then B moves to A and slot k+2 is
 // requested.  (A third buffer -- two slots in flight throughout -- made the pass faster alone and the batch slower: 30-50
-// more registers per lane)
+// more registers per lane, profiles/NOTES.md round 2.)
 template <bool WHB, int MODE>
 __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							 const int16_t *__restrict__ fmdev, size_t fmdev_stride, int n_streams,
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 						const int ld = (int)(int16_t)((vw[t >> 1] >> (16 * (t & 1))) & 0xffff);
 						// sample 8 q + t of the chunk: group 2 q + (t >> 2) of four, component t & 3
 						// (the sample itself is looked at while 4 < bitcnt < 10 only: tfa2.cpp:371-375.  Staging the chunk's 32 samples in
-						// LDS instead of this load-and-wait made the slicers 20 % faster and the batch 3 % slower: DESIGN.md 7d)
+						// LDS instead of this load-and-wait made the slicers 20 % faster and the batch 3 % slower: profiles/NOTES.md round 3)
 						const uint32_t iq = (f.bitcnt > 4 && f.bitcnt < 10) ? drow[g0 + kChunk * i + 8 * q + t] : 0u;
 						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, iq, spb, nb_mul);
 					}
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(64) TFREC_LAT_VGPR_ATTR void slicer_kernel(const ui
 	// qsel: 0 = long windows (heads), then short ones; 1 = only the long windows' heads; 2 = only the short windows
 	// the lanes' 32-sample chunk, a column each: 8 KB for TFA_1 (32 dwords per lane), 4 KB for the TFA_2 family (32 int16).
 	// Dynamic, so that the TFA_2-family launch holds half: these waves live for milliseconds, six of them per CU, and the
-	// front end beside them needs 16.6 KB per workgroup of what the CU's 160 KB have left
+	// front end beside them needs 16.6 KB per workgroup of what the CU's 160 KB have left (profiles/NOTES.md round 3)
 	extern __shared__ uint4 slot_lds[];
 	latency_prio();
 #ifdef TFREC_AMD_SLICER_CLAIM  // (sensitivity experiment: -DTFREC_AMD_SLICER_CLAIM='"v175"' makes the kernel hold that many registers)
@@ -1523,7 +1523,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		return v;
 	};
 #ifdef TFREC_AMD_COOPSTAT
-	unsigned long long cs_steps = 0, cs_acc = 0, cs_rej = 0, cs_slow = 0;
+	unsigned long long cs_steps = 0, cs_acc = 0, cs_rej = 0, cs_slow = 0, cs_full = 0, cs_pop = 0, cs_cont = 0;
 #endif
 	// The walk over one step's candidates when the step lies in ONE block (all but one in 128): last_bit_idx is brought to
 	// that block, and the rest is plain scalar arithmetic on indices relative to the step -- an accepted edge appends its
@@ -1540,7 +1540,19 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		unsigned long long todo = ~0ull;  // positions not yet visited
 #ifdef TFREC_AMD_COOPSTAT
 		cs_steps++;
+		{
+			const unsigned long long mm = last_bit ? m0 : m1;
+			cs_full += mm == ~0ull;
+			cs_pop += (unsigned long long)__builtin_popcountll(mm);
+			cs_cont += (mm & 1ull) && (ibase - lbi <= 4);  // the step begins inside a run that began before it
+		}
 #endif
+		// (the callers come here only with a candidate of the polarity that can flip last_bit in the step: the first one
+		// visited is the step's -- and, once per window, the window's -- first candidate edge)
+		first_cand_g = first_cand_g < 0 ? gb + __builtin_ctzll(last_bit ? m0 : m1) : first_cand_g;
+		// an edge is accepted iff index - lbi > 8 (tfa2.cpp:391) and td_lo <= index - lbi <= td_hi (:393): ONE unsigned compare
+		const int acc_lo = td_lo > 9 ? td_lo : 9;
+		const uint32_t acc_span = (uint32_t)(td_hi - acc_lo);  // (td_hi >= 32 * 22 - 1: never below acc_lo)
 		while (true) {
 			const unsigned long long m = (last_bit ? m0 : m1) & todo;
 			if (!m)
@@ -1551,23 +1563,19 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 			const int k = __builtin_ctzll(m);
 			todo = ~1ull << k;
 			const int index = ibase + 2 * k, d = index - lbi;
-			if (first_cand_g < 0)
-				first_cand_g = gb + k;
-			if (d > 2)
-				lbi = index;  // tfa2.cpp:410-411 (d was taken first: the edge's timing uses the old value)
-			if (d > 8) {          // tfa2.cpp:391
-				bitcnt++;
-				if (d >= td_lo && d <= td_hi) {  // tdiff > spb / 4 && tdiff < 32 * spb
-					const int numbits = tfa2_numbits_mul(d, nb_mul);
-					const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
-					bw.put_bits((last_bit ? (1u << run) - 1u : 0u) | ((uint32_t)(last_bit ^ 1) << run), run + 1);
-					last_bit ^= 1;
+			lbi = d > 2 ? index : lbi;  // tfa2.cpp:410-411 (d was taken first: the edge's timing uses the old value)
+			bitcnt += d > 8 ? 1 : 0;    // tfa2.cpp:391-392
+			if ((uint32_t)(d - acc_lo) <= acc_span) {
+				const int numbits = tfa2_numbits_mul(d, nb_mul);
+				const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
+				// `run` copies of last_bit, then its complement: ones below bit `run` and a zero there, or zeros and a one
+				bw.put_bits((1u << run) - (uint32_t)last_bit, run + 1);
+				last_bit ^= 1;
 #ifdef TFREC_AMD_COOPSTAT
-					cs_acc++;
-					cs_rej--;
+				cs_acc++;
+				cs_rej--;
 #endif
-					continue;
-				}
+				continue;
 			}
 			// not accepted: the run of candidates of the same polarity right behind it cannot be either (see below); it
 			// only moves last_bit_idx, to the last sample at which "index - lbi > 2" fired
@@ -1725,6 +1733,9 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		atomicAdd(&T.stats[8], cs_acc);
 		atomicAdd(&T.stats[9], cs_rej);
 		atomicAdd(&T.stats[10], cs_slow);
+		atomicAdd(&T.stats[13], cs_full);
+		atomicAdd(&T.stats[14], cs_pop);
+		atomicAdd(&T.stats[15], cs_cont);
 	}
 #endif
 	if (lane == 0) {
@@ -2893,7 +2904,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 // executed for ONE stream per wave, as the exact demodulator kernel does, it is a third of the batch's vector
 // instructions; a row of 16 lanes is all the broadcast needs.  (A lane per stream was tried first: its arithmetic is 45
 // cycles per sample, profiles/ubench/verify_chain.hip, but the flat loop around it -- 16-byte accesses of 64 different rows
-// per instruction, lanes in different groups of a half-step -- ran at 108)
+// per instruction, lanes in different groups of a half-step -- ran at 108; profiles/NOTES.md round 3.)
 // The code below is written per lane; the lanes of a row hold the same stream, window and step throughout, so every
 // branch is uniform per row.  Where the decoder locked, the average was frozen as an integer (whb.cpp:653-654): (int) of
 // the speculated double is the exact one's neighbour once in ~200 locks; that is accepted iff no candidate test of the
@@ -2937,7 +2948,7 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 #endif
 	// Workgroups of FOUR waves (independent: no barrier, no shared memory): a workgroup lands on one CU, a wave on each of
 	// its SIMDs.  As 256 one-wave workgroups the check sat on ONE SIMD of every CU of the chip, and the four-wave workgroups
-	// of the front end and the discriminator pass ran at the pace of their wave on that SIMD.
+	// of the front end and the discriminator pass ran at the pace of their wave on that SIMD (profiles/NOTES.md round 3).
 	const int ln = threadIdx.x & 63, row = ln >> 4, li = ln & 15;
 	const int s = (blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 4 + row;
 	const bool active = s < n_streams;

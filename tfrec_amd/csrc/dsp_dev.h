@@ -84,14 +84,28 @@ __device__ __forceinline__ int fm_dev_nrzs(int ar, int aj, int br, int bj)
 	     for the whole kernel instead of being re-materialised (two s_mov each) at every use */                        \
 	  0x1.a827999fcef32p-2, 0x1.921fb54442d18p-1, 0x1.921fb54442d18p+0, 0x1.921fb54442d18p+1, 16384.0 * (1.0 / 0x1.921fb54442d18p+1) }
 
-__device__ __forceinline__ double atan2_int(double cj, double cr, const double *__restrict__ poly)
+// The octant reduction of atan2_int, apart: num == 0 exactly iff the direction is one of the exactly representable ones
+// (an axis: mn = 0; a diagonal: mx - mn = 0 in the upper half-octant; the origin: mx = 0) -- ONE compare where fm_dev_fast
+// used to test cj == 0, cr == 0 and |cj| == |cr| by themselves (five compares per sample in the discriminator pass).
+struct AtanRed {
+	double num, den;
+	bool upper;
+};
+__device__ __forceinline__ AtanRed atan2_reduce(double cj, double cr, const double *__restrict__ poly)
 {
-	const double kTanPi8 = poly[11], kPi4 = poly[12], kPi2 = poly[13], kPi = poly[14];
+	const double kTanPi8 = poly[11];
 	const double ax = fabs(cr), ay = fabs(cj);
 	const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-	const bool upper = mn > kTanPi8 * mx;  // the angle of (mx, mn) is above pi/8: atan(t) = pi/4 - atan((1-t)/(1+t))
-	const double num = upper ? mx - mn : mn;
-	const double den = upper ? mx + mn : mx;  // exact: integers below 2^33
+	AtanRed r;
+	r.upper = mn > kTanPi8 * mx;  // the angle of (mx, mn) is above pi/8: atan(t) = pi/4 - atan((1-t)/(1+t))
+	r.num = r.upper ? mx - mn : mn;
+	r.den = r.upper ? mx + mn : mx;  // exact: integers below 2^33
+	return r;
+}
+__device__ __forceinline__ double atan2_reduced(const AtanRed &r, double cj, double cr, const double *__restrict__ poly)
+{
+	const double kPi4 = poly[12], kPi2 = poly[13], kPi = poly[14];
+	const double num = r.num, den = r.den;
 	double y = __builtin_amdgcn_rcp(den);
 	double e = __builtin_fma(-den, y, 1.0);
 	y = __builtin_fma(y, e, y);
@@ -105,10 +119,14 @@ __device__ __forceinline__ double atan2_int(double cj, double cr, const double *
 	for (int k = 9; k >= 0; k--)
 		p = __builtin_fma(p, s2, poly[k]);
 	double phi = q * p;
-	phi = upper ? kPi4 - phi : phi;
-	phi = ay > ax ? kPi2 - phi : phi;
+	phi = r.upper ? kPi4 - phi : phi;
+	phi = fabs(cj) > fabs(cr) ? kPi2 - phi : phi;
 	phi = cr < 0.0 ? kPi - phi : phi;
 	return copysign(phi, cj);
+}
+__device__ __forceinline__ double atan2_int(double cj, double cr, const double *__restrict__ poly)
+{
+	return atan2_reduced(atan2_reduce(cj, cr, poly), cj, cr, poly);
 }
 
 // fm_dev, dsp_stuff.cpp:284-292, in the arithmetic of the normative build: (int)(atan2(cj,cr) * (16384/pi)).
@@ -116,7 +134,7 @@ __device__ __forceinline__ double atan2_int(double cj, double cr, const double *
 // glibc returns for them so they do not depend on an approximation's last bits; everywhere else the error of
 // atan2_int (4e-12 in the scaled angle) can only matter when the product is within ~1e-11 of an integer: every
 // sample within 1e-9 is handed to the exact slow path (fm_resolve.h), which decides the truncation as the reference
-// does under a correctly rounded atan2 and logs the sample for the host's libm check at drain time (DESIGN.md 4.8).
+// does under a correctly rounded atan2 and logs the sample for the host's libm check at drain time (DESIGN.md section 4, item 8).
 // Returns the scaled angle; true = generic direction within 1e-9 of a truncation boundary.
 __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out, const double *__restrict__ atan_poly,
 					    double flag_eps = 1e-9)
@@ -128,7 +146,8 @@ __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out,
 	// The exactly representable directions are a handful of samples per batch: ONE wave-uniform test keeps the four-way
 	// divergent chain of cases (a dozen exec-mask instructions per sample, a third of the discriminator pass's scalar
 	// instructions) out of the samples' common path.
-	const bool special = cj == 0.0 || cr == 0.0 || fabs(cj) == fabs(cr);
+	const AtanRed red = atan2_reduce(cj, cr, atan_poly);
+	const bool special = red.num == 0.0;  // cj == 0 || cr == 0 || |cj| == |cr| (see atan2_reduce)
 	if (__builtin_expect(__ballot(special) != 0ull, 0)) {
 		generic = false;
 		if (cj == 0.0) {
@@ -143,7 +162,7 @@ __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out,
 			generic = true;
 		}
 	} else {
-		ang = atan2_int(cj, cr, atan_poly);
+		ang = atan2_reduced(red, cj, cr, atan_poly);
 	}
 	const double v = ang * atan_poly[15];  // kFmScale
 	*v_out = v;

@@ -20,8 +20,8 @@
 // Stage 1 with u8 input uses ((u8-128)*h) >> 10 (identical value, the <<6 cancels).
 //
 // MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  A lane reads the
-// 28 raw bytes of a stage-1 group (4 outputs of both rails) straight from global memory with two unaligned vector
-// loads -- neighbouring lanes overlap, so the tile streams its 8 KiB + 112 B halo once (the halo of a submit's first
+// 44 raw bytes of a stage-1 group (8 outputs of both rails) straight from global memory with three unaligned vector
+// loads -- neighbouring lanes overlap (32-byte stride), so the tile streams its 8 KiB + 112 B halo once (the halo of a submit's first
 // tile comes from the previous submit's tail); stage-1 outputs live only in LDS ((I, Q) float pairs, 16.6 KB per
 // workgroup: the raw bytes used to be staged there too, 25 KB, which capped the kernel at 6 workgroups per CU),
 // read back with ds_read_b128; stage-2 results leave as one 16-byte store per thread, and the trigger bits of
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	__builtin_amdgcn_s_setprio(TFREC_AMD_FE_PRIO);
 #endif
 	const uint8_t *src = iq + (size_t)s * stride;
-	// The tile reads raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) straight from global memory: a lane's 28 bytes per
-	// stage-1 group overlap its neighbours' (16-byte stride), so the second load of a group hits what the first one of
+	// The tile reads raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) straight from global memory: a lane's 44 bytes per
+	// stage-1 group overlap its neighbours' (32-byte stride), so the last load of a group hits what the first one of
 	// the next lane brought in; the 112 bytes before the submit come from the previous one's tail, what lies behind its
 	// end is silence (only the last tile's last groups look there, and their outputs are never used).
 	const long base = 8L * kB * m0 - kTail;

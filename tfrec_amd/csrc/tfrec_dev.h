@@ -253,7 +253,7 @@ struct WinTables {
 	                             // begins locked, the end mark) + the slack whb_verify_kernel's prefetch reads ahead
 	WhbExact *whbx;              // [n_streams] the filter's exact state, carried by whb_verify_kernel (ONE array per context)
 	int32_t *whbfail;            // [n_streams] set by whb_verify_kernel: the stream's speculation failed in this submit
-	// ... and what the exact kernel needs to do such a stream's submit again (DESIGN.md 4.7b):
+	// ... and what the exact kernel needs to do such a stream's submit again (DESIGN.md section 4, item 7):
 	ChainState *whbsnap;         // [n_streams] the WHB chain state whb_demod_kernel<false> started this submit from
 	WhbExact *whbx0;             // [n_streams] the exact filter state whb_verify_kernel started this submit from
 	uint32_t *whbseen;           // [n_streams] whbgen[s] as whb_demod_kernel<false> saw it before it read the state
