@@ -621,12 +621,13 @@ def main():
                     utilisation = {
                         "issue_busy_ms": vj["issue_roof_ms"],
                         "issue_busy_over_period": round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4),
-                        "note": "NOT a roofline and not a capacity: sum over the batch's kernels of SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x "
-                                "2.4 GHz) = wave-quad-cycles with an instruction of any kind in flight.  Waves of one SIMD overlap (a vector "
-                                "and a scalar instruction of two waves take 0.70-0.78 x their sum, profiles/r04_mixed_issue.jsonl), and the "
-                                "front end ALONE already reads more than 100 % by this measure (inst_active_ms > kernel_ms_alone in "
-                                "profiles/%s_valu.json): the period has followed this sum within 5 %% for four rounds, with >= 20 %% of slack "
-                                "in it.  What bounds the path is in `roofline` (hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms)." % ptag,
+                        "note": ("NOT a roofline: the sum over the batch's kernels (each measured alone) of SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs "
+                                 "x 2.36 GHz) = wave-quad-cycles with an instruction of any kind in flight = 1.12 x (VALU + SALU wave instructions).  "
+                                 "The batch period has equalled this sum within 1-5 percent for five rounds (DESIGN.md section 3, 'What binds'): "
+                                 "a descriptive law of this implementation's instruction count -- scalar instructions cost like vector ones --, while "
+                                 "no single resource is saturated (memory controllers 32 percent busy, VALU issue 58 percent, clock 2.36 GHz, LDS and "
+                                 "register footprints without effect: profiles/r05_*.txt).  What bounds the path nominally is in `roofline` "
+                                 "(hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms); source profile: profiles/" + ptag + "_valu.json"),
                         "source": "profiles/%s_valu.json (builder's rocprofv3 --pmc passes; NOT measured in this run)" % ptag,
                     }
                 # the serial floor: the dominant chain kernel ALONE on the chip (serial per stream; consecutive batches'
