@@ -969,6 +969,11 @@ struct Slicer {  // window-local demodulator state (tfa1.h:28-32, tfa2.h:35-42)
 	int bitcnt, dmin, dmax, offset, last_bit;      // tfa2
 	int first_cand_g;
 	int td_lo, td_hi;  // tfa2.cpp:393 "tdiff > spb / 4 && tdiff < 32 * spb" for the integer tdiff: td_lo <= tdiff <= td_hi
+	// The lane-per-window loop walks a window in 32-sample chunks.  demodulator::start (decoder.cpp:118-122) rebases
+	// last_bit_idx at every block start; a chunk holds at most one block start, at its sample `split` (>= 32: none): the
+	// per-sample form of this bookkeeping (block of the sample, compare, rebase, index) was a fifth of a sample's instructions
+	int ib;     // index (decoder.h:72 units: 2 per sample) of the chunk's first sample relative to block cur_block
+	int split;  // sample of the chunk at which block cur_block + 1 begins
 	int hi, lo;  // tfa2.cpp:379-381: noffset + dmax / 32, noffset + dmin / 32 -- functions of (offset, dmax, dmin), which only move
 	             // while bitcnt < 10: kept instead of recomputed at every sample (a conversion to double and back, a product
 	             // and two range compares per sample of a loop that runs at a lone wave's issue rate)
@@ -994,16 +999,36 @@ __device__ __forceinline__ void slicer_fresh(Slicer &f, int kind)
 	(void)kind;
 }
 
-// One sample of tfa1_demod::demod inside a window (tfa1.cpp:150-178); the flush at the window's last sample
-// is done by the caller.  (BITPERIOD 10: ones are emitted for n = 22, 42, ... <= gap.)
-__device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int g, int I, int Q, int pI, int pQ)
+// the chunk that begins at sample gf: last_bit_idx to the block of its first sample, where the next block begins in it
+__device__ __forceinline__ void slicer_chunk_begin(Slicer &f, int gf)
 {
-	const int b = g >> 13;
+	const int b = gf >> 13;
 	if (b != f.cur_block) {
 		f.lbi = rebase_lbi(f.lbi, f.cur_block, b);
 		f.cur_block = b;
 	}
-	const int index = 2 * (g & (kBlockDec - 1));
+	const int o = gf & (kBlockDec - 1);
+	f.ib = 2 * o;
+	f.split = kBlockDec - o;
+}
+// sample k of the chunk: its index; crossing into the next block is rare and tested for the whole wave at once
+__device__ __forceinline__ int slicer_index(Slicer &f, int k)
+{
+	if (__builtin_expect(__ballot(k == f.split) != 0ull, 0)) {
+		if (k == f.split) {
+			f.lbi = rebase_lbi(f.lbi, f.cur_block, f.cur_block + 1);
+			f.cur_block++;
+			f.ib -= kIndexSpan;
+		}
+	}
+	return f.ib + 2 * k;
+}
+
+// One sample of tfa1_demod::demod inside a window (tfa1.cpp:150-178); the flush at the window's last sample
+// is done by the caller.  (BITPERIOD 10: ones are emitted for n = 22, 42, ... <= gap.)
+__device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int k, int I, int Q, int pI, int pQ)
+{
+	const int index = slicer_index(f, k);
 	const int dev = fm_dev_nrzs(I, Q, pI, pQ);
 	if (dev > f.mark_lvl)
 		f.mark_lvl = dev;
@@ -1027,9 +1052,8 @@ __device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int g, int
 
 // A candidate edge at sample g (tfa2.cpp:383-411: outside the dead band, bit != last_bit): glitch rule, edge timing, the
 // bits it emits, last_bit_idx.  (The caller has brought last_bit_idx to g's block.)
-__device__ __forceinline__ void tfa2_candidate(Slicer &f, BitWriter &bw, int g, int bit, double spb, uint64_t nb_mul)
+__device__ __forceinline__ void tfa2_candidate(Slicer &f, BitWriter &bw, int g, int index, int bit, double spb, uint64_t nb_mul)
 {
-	const int index = 2 * (g & (kBlockDec - 1));
 	if (f.first_cand_g < 0)
 		f.first_cand_g = g;
 	if (index > f.lbi + 8) {
@@ -1049,13 +1073,9 @@ __device__ __forceinline__ void tfa2_candidate(Slicer &f, BitWriter &bw, int g, 
 
 // One sample of tfa2_demod::demod inside a window (tfa2.cpp:357-412), ld = (int)iir->step(fm_dev(...)).
 // iq: the decimated sample itself (looked at while 4 < bitcnt < 10 only: tfa2.cpp:371-375)
-__device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int ld, uint32_t iq, double spb, uint64_t nb_mul)
+__device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int k, int ld, uint32_t iq, double spb, uint64_t nb_mul)
 {
-	const int b = g >> 13;
-	if (b != f.cur_block) {
-		f.lbi = rebase_lbi(f.lbi, f.cur_block, b);
-		f.cur_block = b;
-	}
+	const int index = slicer_index(f, k);
 	if (f.bitcnt < 10) {
 		const bool up = ld > f.dmax, down = ld < f.dmin;
 		if (up)
@@ -1075,7 +1095,7 @@ __device__ __forceinline__ void tfa2_sample(Slicer &f, BitWriter &bw, int g, int
 	const int hi = f.hi, lo = f.lo;
 	const int bit = ld > hi ? 1 : 0;
 	if ((ld > hi || ld < lo) && bit != f.last_bit)
-		tfa2_candidate(f, bw, g, bit, spb, nb_mul);
+		tfa2_candidate(f, bw, g, index, bit, spb, nb_mul);
 }
 
 // Run one window [g0, last] of a TFA_1 (KIND 0) or TFA_2-family (KIND 1) slicer.  `f` carries the state in and
@@ -1128,6 +1148,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 			my_lds[4 * 64] = cur.q4; my_lds[5 * 64] = cur.q5; my_lds[6 * 64] = cur.q6; my_lds[7 * 64] = cur.q7;
 			const Slot8 nxt = load(i + 1 < nch ? i + 1 : i);
 			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+			slicer_chunk_begin(f, g0 + kChunk * i);
 			uint4 vn = my_lds[0];
 #pragma unroll 1
 			for (int q = 0; 4 * q < nv; q++) {
@@ -1138,7 +1159,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 				for (int t = 0; t < 4; t++) {
 					const int I = (int)(int16_t)(vw[t] & 0xffff), Q = (int)vw[t] >> 16;
 					if (4 * q + t < nv)
-						tfa1_sample(f, bw, g0 + kChunk * i + 4 * q + t, I, Q, pI, pQ);
+						tfa1_sample(f, bw, 4 * q + t, I, Q, pI, pQ);
 					pI = I;
 					pQ = Q;
 				}
@@ -1159,6 +1180,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 			my_lds[0 * 64] = cur.q0; my_lds[1 * 64] = cur.q1; my_lds[2 * 64] = cur.q2; my_lds[3 * 64] = cur.q3;
 			const Slot4 nxt = load(i + 1 < nch ? i + 1 : i);
 			const int nv = n - kChunk * i < kChunk ? n - kChunk * i : kChunk;
+			slicer_chunk_begin(f, g0 + kChunk * i);
 			uint4 vn = my_lds[0];
 #pragma unroll 1
 			for (int q = 0; 8 * q < nv; q++) {
@@ -1173,7 +1195,7 @@ __device__ __forceinline__ int run_window(Slicer &f, BitWriter &bw, int g0, int 
 						// (the sample itself is looked at while 4 < bitcnt < 10 only: tfa2.cpp:371-375.  Staging the chunk's 32 samples in
 						// LDS instead of this load-and-wait made the slicers 20 % faster and the batch 3 % slower: profiles/NOTES.md round 3)
 						const uint32_t iq = (f.bitcnt > 4 && f.bitcnt < 10) ? drow[g0 + kChunk * i + 8 * q + t] : 0u;
-						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, ld, iq, spb, nb_mul);
+						tfa2_sample(f, bw, g0 + kChunk * i + 8 * q + t, 8 * q + t, ld, iq, spb, nb_mul);
 					}
 				}
 			}
