@@ -1030,10 +1030,10 @@ __device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int k, int
 {
 	const int index = slicer_index(f, k);
 	const int dev = fm_dev_nrzs(I, Q, pI, pQ);
-	if (dev > f.mark_lvl)
-		f.mark_lvl = dev;
-	else
-		f.mark_lvl = tfa1_decay(f.mark_lvl);
+	{  // (both sides evaluated, then selected: as a branch the decay cost the wave three scalar mask instructions per sample)
+		const int decayed = tfa1_decay(f.mark_lvl);
+		f.mark_lvl = dev > f.mark_lvl ? dev : decayed;
+	}
 	if (f.mark_lvl > f.rssi_i)
 		f.rssi_i = f.mark_lvl;
 	if (dev < f.mark_lvl / 2) {
