@@ -141,25 +141,28 @@ __device__ __forceinline__ bool fm_dev_fast(double cr, double cj, double *v_out,
 {
 	const double kPi = 0x1.921fb54442d18p+1, kPi2 = 0x1.921fb54442d18p+0, kPi4 = 0x1.921fb54442d18p-1,
 		     k3Pi4 = 0x1.2d97c7f3321d2p+1;
-	// The generic evaluation for every lane, straight-line (a special direction -- a handful of samples per batch -- gives
-	// it num = 0 and, at the origin, a reciprocal of zero: garbage that the rare branch below replaces; nothing traps).  As
-	// "one wave-uniform test, then either path" the compiler built a dozen scalar mask instructions around every sample.
-	const AtanRed red = atan2_reduce(cj, cr, atan_poly);
-	double ang = atan2_reduced(red, cj, cr, atan_poly);
-	const bool special = red.num == 0.0;  // cj == 0 || cr == 0 || |cj| == |cr| (see atan2_reduce)
+	double ang;
 	bool generic = true;
+	// The exactly representable directions are a handful of samples per batch: ONE wave-uniform test keeps the four-way
+	// divergent chain of cases (a dozen exec-mask instructions per sample, a third of the discriminator pass's scalar
+	// instructions) out of the samples' common path.
+	const AtanRed red = atan2_reduce(cj, cr, atan_poly);
+	const bool special = red.num == 0.0;  // cj == 0 || cr == 0 || |cj| == |cr| (see atan2_reduce)
 	if (__builtin_expect(__ballot(special) != 0ull, 0)) {
+		generic = false;
 		if (cj == 0.0) {
 			const bool pos = cr > 0.0 || (cr == 0.0 && !signbit(cr));
 			ang = copysign(pos ? 0.0 : kPi, cj);
-			generic = false;
 		} else if (cr == 0.0) {
 			ang = copysign(kPi2, cj);
-			generic = false;
 		} else if (fabs(cj) == fabs(cr)) {
 			ang = copysign(cr > 0.0 ? kPi4 : k3Pi4, cj);
-			generic = false;
+		} else {
+			ang = atan2_int(cj, cr, atan_poly);
+			generic = true;
 		}
+	} else {
+		ang = atan2_reduced(red, cj, cr, atan_poly);
 	}
 	const double v = ang * atan_poly[15];  // kFmScale
 	*v_out = v;
