@@ -2,31 +2,31 @@
 (fused multiply-adds emulated in 80-bit), against libm atan2 and an 80-bit reference.  python atan_check.py"""
 import numpy as np
 ld = np.longdouble
-C = [float.fromhex(h) for h in ['0x1.fffffffffffffp-1', '-0x1.5555555555101p-2', '0x1.9999999915220p-3', '-0x1.249248f459b71p-3', '0x1.c71c601c68b53p-4', '-0x1.745b3a024febep-4', '0x1.3af4788c30195p-4', '-0x1.0fc0caec4e264p-4', '0x1.cf80524e56f02p-5', '-0x1.5cd7a4fac9dc7p-5', '0x1.47f65fb716232p-6']]
-kPi = float.fromhex('0x1.921fb54442d18p+1'); kPi2 = kPi/2; kPi4 = kPi/4
+C = [float.fromhex(h) for h in ['0x1.45f306dc9c882p+12', '-0x1.b2995e7b7b081p+10', '0x1.04c26be35c182p+10', '-0x1.748375510427cp+9', '0x1.21bb891314681p+9', '-0x1.da194d380517ep+8', '0x1.91035b898ba13p+8', '-0x1.5a01bce7521ebp+8', '0x1.2712f5dc022c6p+8', '-0x1.bc28ee7da8cf2p+7', '0x1.a1931f2ab065cp+6']]
+kPi = float.fromhex('0x1.921fb54442d18p+1')
 kTan = float(np.tan(ld(np.pi)/8))
 kScale = 16384.0 * (1.0 / kPi)
 def fma(a, b, c):
     return (a.astype(ld) * b.astype(ld) + np.asarray(c, dtype=ld)).astype(np.float64)
 def fast(cj, cr):
+    """atan2_reduced of dsp_dev.h: the scaled angle (coefficients carry 16384/pi; reflections about 4096, 8192, 16384)"""
     ax, ay = np.abs(cr), np.abs(cj)
     mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
     upper = mn > kTan * mx
     num = np.where(upper, mx - mn, mn); den = np.where(upper, mx + mn, mx)
-    y = (1.0 / den).astype(np.float32).astype(np.float64)   # a crude rcp, like v_rcp_f64's worst case
-    e = fma(-den, y, 1.0); y = fma(y, e, y)
-    e = fma(-den, y, 1.0); y = fma(y, e, y)
+    y = (1.0 / den).astype(np.float32).astype(np.float64)   # a crude rcp, like v_rcp_f64's worst case (2^-24)
+    e = fma(-den, y, 1.0); y = fma(y, e, y)                  # ONE Newton step
     q = num * y
-    rr = fma(-den, q, num); q = fma(rr, y, q)
+    rr = fma(-den, q, num); q = fma(rr, y, q)                # the quotient corrected with its exact residual
     s2 = q * q
     p = np.full_like(q, C[10])
     for c in C[9::-1]:
         p = fma(p, s2, c)
-    phi = q * p
-    phi = np.where(upper, kPi4 - phi, phi)
-    phi = np.where(ay > ax, kPi2 - phi, phi)
-    phi = np.where(cr < 0, kPi - phi, phi)
-    return np.copysign(phi, cj)
+    t = q * p
+    t = np.where(upper, 4096.0 - t, t)
+    t = np.where(ay > ax, 8192.0 - t, t)
+    t = np.where(cr < 0, 16384.0 - t, t)
+    return np.copysign(t, cj)
 rng = np.random.default_rng(1)
 worst = 0; bad = 0; n_tot = 0; near = 0
 for it in range(40):
@@ -44,8 +44,8 @@ for it in range(40):
     gen = (cj != 0) & (cr != 0) & (np.abs(cj) != np.abs(cr))
     cr, cj = cr[gen], cj[gen]
     v_ref = np.arctan2(cj, cr) * kScale
-    v = fast(cj, cr) * kScale
-    truth = (np.arctan2(cj.astype(ld), cr.astype(ld)) * (ld(16384) / ld(np.pi)))
+    v = fast(cj, cr)
+    truth = (np.arctan2(cj.astype(ld), cr.astype(ld)) * ld(kScale))   # the reference's factor, exactly
     worst = max(worst, float(np.max(np.abs(v.astype(ld) - truth))))
     bad += int(np.sum(np.trunc(v) != np.trunc(v_ref)))
     near += int(np.sum(np.abs(v_ref - np.rint(v_ref)) < 1e-9))

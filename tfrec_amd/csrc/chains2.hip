@@ -799,11 +799,14 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 				}
 			} else {
 				seg_advance(pp, T, c, M, count);
-				A = B;
-				ckA = ckB;
-				fetch(B, ckB);
 			}
 		}
+		// (for every lane, busy or not: as part of the branch above the buffers -- loop-carried in both of its arms -- cost
+		// the finishing arm a copy of every register too, ~65 moves per slot instead of 22)
+		A = B;
+		ckA = ckB;
+		if (busy)
+			fetch(B, ckB);
 		k3_store_t<WHB>(k3_tile, dst);
 	}
 }

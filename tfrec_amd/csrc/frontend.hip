@@ -19,14 +19,15 @@
 // once: one VALU instruction per tap and complex sample, where the integer form (v_mul_hi_i32_i24 + add) took 3.5.
 // Stage 1 with u8 input uses ((u8-128)*h) >> 10 (identical value, the <<6 cancels).
 //
-// MI355X mapping: one 256-thread workgroup per tile of 1024 decimated outputs of one stream.  A lane reads the
-// 44 raw bytes of a stage-1 group (8 outputs of both rails) straight from global memory with three unaligned vector
-// loads -- neighbouring lanes overlap (32-byte stride), so the tile streams its 8 KiB + 112 B halo once (the halo of a submit's first
-// tile comes from the previous submit's tail); stage-1 outputs live only in LDS ((I, Q) float pairs, 16.6 KB per
-// workgroup: the raw bytes used to be staged there too, 25 KB, which capped the kernel at 6 workgroups per CU),
-// read back with ds_read_b128; stage-2 results leave as one 16-byte store per thread, and the trigger bits of
-// 64 consecutive samples are packed into one 64-bit word per wave-quarter with wave ballots.  No MFMA: the
-// path is a streaming stencil with a per-tap rounding, bound by HBM bytes and VALU issue.
+// MI355X mapping: one 256-thread workgroup per tile of 2048 decimated outputs of one stream (kFrontOut = 8 per thread).
+// A lane reads the 76 raw bytes of a stage-1 group (16 outputs of both rails) straight from global memory with five
+// unaligned vector loads -- neighbouring lanes overlap by 12 bytes (64-byte stride), so the tile streams its 16 KiB +
+// 112 B halo once (the halo of a submit's first tile comes from the previous submit's tail); stage-1 outputs live only
+// in LDS ((I, Q) float pairs, 37 KB per workgroup, a pad of 16 bytes behind every lane's 128), read back with
+// ds_read_b128; stage-2 results leave as two 16-byte stores per thread, and the trigger bits of 64 consecutive samples
+// are packed into one 64-bit word per 8 lanes with DPP.  No MFMA: the path is a streaming stencil with a per-tap
+// rounding, bound by HBM bytes and VALU issue.  (Round 2-4 made 4 outputs per thread: the same FMAs, but 16 % more byte
+// conversions -- the overlap is per group --, twice the scalar and address work per output: profiles/NOTES.md round 5.)
 #include <stdlib.h>
 
 #include "dsp_dev.h"
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	__builtin_amdgcn_s_setprio(TFREC_AMD_FE_PRIO);
 #endif
 	const uint8_t *src = iq + (size_t)s * stride;
-	// The tile reads raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) straight from global memory: a lane's 44 bytes per
-	// stage-1 group overlap its neighbours' (32-byte stride), so the last load of a group hits what the first one of
+	// The tile reads raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) straight from global memory: a lane's 76 bytes per
+	// stage-1 group overlap its neighbours' (64-byte stride), so the last load of a group hits what the first one of
 	// the next lane brought in; the 112 bytes before the submit come from the previous one's tail, what lies behind its
 	// end is silence (only the last tile's last groups look there, and their outputs are never used).
 	const long base = 8L * kB * m0 - kTail;
@@ -87,12 +88,12 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTail + 16 * tid);
 
-	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i]; a lane makes kG1 = 8 consecutive outputs of both rails (one pass of the
-	// 256 lanes makes the tile's 2*T; as two passes of four outputs each a lane converted 56 bytes instead of 44 and the
-	// loop's scalar work ran twice).  Outputs k..k+7 need x[2k-6 .. 2k+15]: 44 raw bytes at offset base + 12 + 32*grp
-	// (k = 2*m0 - 22 + 8*grp).  The tile needs 2*T + 24: the last 24 one per lane (below).
-	constexpr int kG1 = 8;
-	constexpr int kDw1 = (2 * kG1 + 6) * kB / 2;  // raw dwords per group: 11 (u8) / 22 (int16)
+	// ---- stage 1: LDS slot i <-> y1[2*m0 - 22 + i] (slot i at y1[y1_phys(i)]); a lane makes kG1 = 2 * kFrontOut consecutive
+	// outputs of both rails (one pass of the 256 lanes makes the tile's 2*T).  Outputs k..k+kG1-1 need x[2k-6 .. 2k+2*kG1-1]:
+	// 4*kG1 + 12 raw bytes at offset base + 12 + 4*kG1*grp (k = 2*m0 - 22 + kG1*grp).  The tile needs 2*T + 24: the last 24
+	// one per lane (below).
+	constexpr int kG1 = kY1Group;
+	constexpr int kDw1 = (2 * kG1 + 6) * kB / 2;  // raw dwords per group: 19 (u8) / 38 (int16) for 16 outputs, 11 / 22 for 8
 	static_assert((2 * kTileDec) / kG1 == kFrontThreads, "one full pass");
 	typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(4)));
 	typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
@@ -112,14 +113,14 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 					rp[4 * q] = v.x; rp[4 * q + 1] = v.y; rp[4 * q + 2] = v.z; rp[4 * q + 3] = v.w;
 				}
 				constexpr int kRest = kDw1 % 4, kDone = kDw1 - kRest;
-				if (kRest == 3) {
+				if constexpr (kRest == 3) {
 					const u32x3_u v = *reinterpret_cast<const u32x3_u *>(gp + 4 * kDone);
 					rp[kDone] = v.x; rp[kDone + 1] = v.y; rp[kDone + 2] = v.z;
-				} else if (kRest == 2) {
+				} else if constexpr (kRest == 2) {
 					const u32x2_u v = *reinterpret_cast<const u32x2_u *>(gp + 4 * kDone);
 					rp[kDone] = v.x; rp[kDone + 1] = v.y;
 				}
-				static_assert(kRest == 3 || kRest == 2, "11 or 22 dwords");
+				static_assert(kRest == 3 || kRest == 2, "19 / 38 or 11 / 22 dwords");
 			} else {
 #pragma unroll
 				for (int q = 0; q < kDw1; q++)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		}
 #pragma unroll
 		for (int q = 0; q < kG1 / 2; q++)
-			*reinterpret_cast<f32x4 *>(&y1[kG1 * grp + 2 * q]) = f32x4{ oy[2 * q].x, oy[2 * q].y, oy[2 * q + 1].x, oy[2 * q + 1].y };
+			*reinterpret_cast<f32x4 *>(&y1[kY1Stride * grp + 2 * q]) = f32x4{ oy[2 * q].x, oy[2 * q].y, oy[2 * q + 1].x, oy[2 * q + 1].y };
 	}
 	// ---- ... and the 24 stage-1 outputs behind them (slots 2*T .. 2*T + 23: the far end of the tile's last stage-2
 	// windows), ONE per lane of the first 24: 8 samples = 16 raw bytes (x kB) at offset 4*slot + 12.  As a third pass of the
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 				const float hs = (float)kS1[n] * (1.0f / 65536.0f);
 				acc = __builtin_elementwise_fma(f32x2{ (float)(int)(int16_t)(rp[n] & 0xffff), (float)((int)rp[n] >> 16) }, f32x2{ hs, hs }, acc);
 			}
-			y1[slot] = f32x2{ (float)(int)(int16_t)(__float_as_uint(acc.x) & 0xffffu), (float)(int)(int16_t)(__float_as_uint(acc.y) & 0xffffu) };
+			y1[y1_phys(slot)] = f32x2{ (float)(int)(int16_t)(__float_as_uint(acc.x) & 0xffffu), (float)(int)(int16_t)(__float_as_uint(acc.y) & 0xffffu) };
 		} else {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
@@ -215,45 +216,49 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 				acc = __builtin_elementwise_fma(f32x2{ (float)(signed char)(w), (float)(signed char)(w >> 8) }, f32x2{ h0, h0 }, acc);
 				acc = __builtin_elementwise_fma(f32x2{ (float)(signed char)(w >> 16), (float)((int)w >> 24) }, f32x2{ h1, h1 }, acc);
 			}
-			y1[slot] = acc - f32x2{ kMagic, kMagic };
+			y1[y1_phys(slot)] = acc - f32x2{ kMagic, kMagic };
 		}
 	}
 	__syncthreads();
 
-	// ---- stage 2: lane makes outputs m0 + 4*tid + {0..3}; output o needs LDS slots [8*tid + 4 + 2*o, +20).
+	// ---- stage 2: lane makes outputs m0 + R*tid + {0..R-1} (R = kFrontOut); output o needs LDS slots [2*R*tid + 4 + 2*o, +20).
 	// Same form as stage 1: acc = fma(y, h / 65536, acc) adds exactly floor(y * h / 65536) = (y * h) >> 16 -- the FMA
 	// rounds once, after the exact product, so it does not matter that y * h (up to 31 bits) is not an fp32 number; the
 	// 20 per-tap terms sum to less than 2^16, so acc stays in [2^23, 2^24).  One v_pk_fma_f32 per tap for both rails
 	// (the integer form: v_mul_hi_i32_i24 + an add per tap and rail).  The int16 store of the reference
 	// (dsp_stuff.cpp:196) is the low half of acc's mantissa: the magic constant has no bits there.
-	f32x2 y[28];
+	constexpr int R = kFrontOut;
+	f32x2 y[2 * R + 18];
 #pragma unroll
-	for (int i = 0; i < 14; i++) {
-		const f32x4 a = *reinterpret_cast<const f32x4 *>(&y1[8 * tid + 4 + 2 * i]);
+	for (int i = 0; i < R + 9; i++) {
+		const f32x4 a = *reinterpret_cast<const f32x4 *>(&y1[kY1Stride * tid + y1_phys(4 + 2 * i)]);
 		y[2 * i] = f32x2{ a.x, a.y };
 		y[2 * i + 1] = f32x2{ a.z, a.w };
 	}
-	uint32_t outw[4];
-	uint32_t nib = 0;  // trigger bits of the lane's four samples
+	uint32_t outw[R];
+	uint32_t nib = 0;  // trigger bits of the lane's R samples
 	// u8 input: the sums stay below 2^14 in magnitude (|y1| <= 8526, |y2| <= 12153 with the wide taps), so the int16 store
 	// changes nothing and acc - 2^23 - 2^22 IS the sample: |I| + |Q| > thresh (fm_demod.cpp:45, tfa1.cpp:147) is evaluated on
 	// the floats -- exact integers below 2^17 --, as the sign of (thresh + 0.5) - (|I| + |Q|) (never zero: x - x would be -0
 	// in this kernel's rounding mode).  5 instructions per sample instead of 9 and no compare / select pairs with their
 	// wait states; the 16-bit halves are packed by one v_perm_b32.
 	const float thresh_h = (float)thresh + 0.5f;
-	f32x2 acc4[4] = { { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic }, { kMagic, kMagic } };
+	f32x2 accs[R];
+#pragma unroll
+	for (int o = 0; o < R; o++)
+		accs[o] = f32x2{ kMagic, kMagic };
 #pragma unroll
 	for (int n = 0; n < 20; n++) {
 #pragma unroll
-		for (int o = 0; o < 4; o++)
-			acc4[o] = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc4[o]);
-		// a tap's four FMAs go to four accumulators: none waits for the one before it (chained per accumulator, a packed FMA
+		for (int o = 0; o < R; o++)
+			accs[o] = __builtin_elementwise_fma(y[2 * o + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, accs[o]);
+		// a tap's FMAs go to R accumulators: none waits for the one before it (chained per accumulator, a packed FMA
 		// needs a wait state before its successor)
 		__builtin_amdgcn_sched_barrier(0);
 	}
 #pragma unroll
-	for (int o = 0; o < 4; o++) {
-		const f32x2 acc = acc4[o];
+	for (int o = 0; o < R; o++) {
+		const f32x2 acc = accs[o];
 		if (IN16) {  // int16 input: the reference's int16 store can wrap (dsp_stuff.cpp:196): integer path
 			const int oI = (int)(int16_t)(__float_as_uint(acc.x) & 0xffffu), oQ = (int)(int16_t)(__float_as_uint(acc.y) & 0xffffu);
 			outw[o] = ((uint32_t)oI & 0xffffu) | ((uint32_t)oQ << 16);
@@ -265,22 +270,34 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			outw[o] = __builtin_amdgcn_perm(__float_as_uint(acc.y), __float_as_uint(acc.x), 0x05040100u);
 		}
 	}
-	*reinterpret_cast<uint4 *>(dec + (size_t)s * dec_stride + m0 + 4 * tid) =
-		make_uint4(outw[0], outw[1], outw[2], outw[3]);
+#pragma unroll
+	for (int q = 0; q < R / 4; q++)
+		*reinterpret_cast<uint4 *>(dec + (size_t)s * dec_stride + m0 + R * tid + 4 * q) =
+			make_uint4(outw[4 * q], outw[4 * q + 1], outw[4 * q + 2], outw[4 * q + 3]);
 
-	// ---- trigger mask: bit b of word w <-> decimated sample 64*w + b.  Lane l holds samples 4*l .. 4*l+3 of its wave's
-	// 256: a nibble at bit 4*(l & 15) of word l >> 4.  Lanes 0-7 of a row of 16 fill the word's low dword, lanes 8-15 its
-	// high dword: shift the nibble within a dword, OR over the 8 lanes with three DPP steps, fetch the other half.
+	// ---- trigger mask: bit b of word w <-> decimated sample 64*w + b.  Lane l holds samples R*l .. R*l+R-1 of its wave's
+	// 64*R.  R = 4: a nibble at bit 4*(l & 15) of word l >> 4; lanes 0-7 of a row of 16 fill the word's low dword, lanes
+	// 8-15 its high dword: shift the nibble within a dword, OR over the 8 lanes with three DPP steps, fetch the other half.
+	// R = 8: a byte at bit 8*(l & 7) of word l >> 3; a quad fills a dword (two DPP steps), the next quad is the high half.
 	// (Built from four ballots with bit-spreading arithmetic this was a quarter of the kernel's vector instructions.)
 	{
 		const int lane = tid & 63, wave = tid >> 6;
-		uint32_t v = nib << (4 * (lane & 7));
-		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-		v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror: the other quad of the 8
-		const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8: lane + 8's
-		if ((lane & 15) == 0)
-			mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + (lane >> 4)] = ((unsigned long long)hi << 32) | v;
+		if (R == 4) {
+			uint32_t v = nib << (4 * (lane & 7));
+			v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+			v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+			v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror: the other quad of the 8
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8: lane + 8's
+			if ((lane & 15) == 0)
+				mask[(size_t)s * mask_stride + (m0 >> 6) + 4 * wave + (lane >> 4)] = ((unsigned long long)hi << 32) | v;
+		} else {
+			uint32_t v = nib << (8 * (lane & 3));
+			v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+			v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);  // row_shl:4: lane + 4's
+			if ((lane & 7) == 0)
+				mask[(size_t)s * mask_stride + (m0 >> 6) + 8 * wave + (lane >> 3)] = ((unsigned long long)hi << 32) | v;
+		}
 	}
 
 	// ---- the decimated sample BEFORE this submit's first one (it comes out of the carried raw history; zero history
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		f32x2 acc = { kMagic, kMagic };
 #pragma unroll
 		for (int n = 0; n < 20; n++)
-			acc = __builtin_elementwise_fma(y1[2 + n], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc);
+			acc = __builtin_elementwise_fma(y1[y1_phys(2 + n)], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc);
 		prevdec[s] = (__float_as_uint(acc.x) & 0xffffu) | (__float_as_uint(acc.y) << 16);
 	}
 }
@@ -300,13 +317,13 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 // 256 samples (one wave) is computed iff a trigger lies in it or within `wmax` samples before it (wmax = the longest
 // window of the registered demodulators; the first wmax samples always, a window may be open from the previous
 // submit) -- about half of the benchmark workload.  Same 256 x 4 lane layout as the front end.
-__global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
+__global__ __launch_bounds__(kFmThreads) void fmdev_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							      const unsigned long long *__restrict__ mask, size_t mask_stride,
 							      const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
 							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax, double flag_eps)
 {
 	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-	const int m0 = tile * kTileDec;
+	const int m0 = tile * kFmTile;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	// Wave priority 1: the pass heads the TFA_2 family's biquad stream, one of the two chains that end at the period.  At
 	// priority 0 the pipeline has two stable states -- this pass 1.8 ms inside the batch and the batch 6.6 ms, or 2.7 and
@@ -331,15 +348,35 @@ __global__ __launch_bounds__(kFrontThreads) void fmdev_kernel(const uint32_t *__
 	const uint4 v = *reinterpret_cast<const uint4 *>(drow + m0 + 4 * tid);
 	const uint32_t pw = (m0 + 4 * tid) > 0 ? drow[m0 + 4 * tid - 1] : prevdec[s];
 	const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
-	int pI = (int)(int16_t)(pw & 0xffff), pQ = (int)pw >> 16;
 	int dv[4];
 	bool unc[4];
+	// The cross terms (dsp_stuff.cpp:288-289) as 32-bit integers: cr = I*pI + Q*pQ is one v_dot2_i32_i16 on the packed
+	// samples as they are stored, cj = Q*pI - I*pQ two 24-bit multiplies.  |cj| < 2^31 always; cr wraps only for
+	// I = Q = pI = pQ = -32768, where cj = 0: an exact direction, and those are recomputed in fp64 below.  (In fp64 from
+	// the start: four conversions, four products and two sums per sample instead of seven instructions.)
+	typedef short s16x2 __attribute__((ext_vector_type(2)));
+	uint32_t pword = pw;
+	int pI = (int)(int16_t)(pw & 0xffff), pQ = (int)pw >> 16;
 #pragma unroll
 	for (int o = 0; o < 4; o++) {
 		const int I = (int)(int16_t)(w4[o] & 0xffff), Q = (int)w4[o] >> 16;
-		double v;
-		unc[o] = fm_dev_fast(((double)I) * pI + ((double)Q) * pQ, ((double)Q) * pI - ((double)I) * pQ, &v, kAtanPolyFront, flag_eps);
-		dv[o] = (int)v;  // |v| <= 16384: the range tests of d2i (x86's out-of-range result) can never fire
+		const int cr = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, w4[o]), __builtin_bit_cast(s16x2, pword), 0, false);
+		const int cj = Q * pI - I * pQ;  // (16-bit factors: v_mul_i32_i24 / v_mad_i32_i24)
+		const double crd = (double)cr, cjd = (double)cj;
+		const AtanRed red = atan2_reduce(cjd, crd, kAtanPolyFront);
+		double sv;
+		// The exactly representable directions (cj == 0 || cr == 0 || |cj| == |cr|: red.num == 0, see atan2_reduce) are
+		// one sample in 2500 of a noise stream: ONE wave-uniform test keeps their divergent chain of cases out of the common
+		// path.  (One test for a lane's four samples -- four straight-line evaluations side by side -- was tried: a tenth of
+		// the waves then take the slow branch, and 74 registers instead of 28 made the pass 60 % slower inside the batch.)
+		if (__builtin_expect(__ballot(red.num == 0.0) != 0ull, 0)) {
+			unc[o] = fm_dev_fast(((double)I) * pI + ((double)Q) * pQ, ((double)Q) * pI - ((double)I) * pQ, &sv, kAtanPolyFront, flag_eps);
+		} else {
+			sv = atan2_reduced(red, cjd, crd, kAtanPolyFront);
+			unc[o] = fabs(sv - rint(sv)) < flag_eps;
+		}
+		dv[o] = (int)sv;  // |v| <= 16384: the range tests of d2i (x86's out-of-range result) can never fire
+		pword = w4[o];
 		pI = I;
 		pQ = Q;
 	}
@@ -565,8 +602,8 @@ hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, 
 			int n_streams, int n_blocks, int wmax, double flag_eps)
 {
 	const int m_total = n_blocks * kBlockDec;
-	dim3 grid(m_total / kTileDec, n_streams);
-	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFrontThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
+	dim3 grid(m_total / kFmTile, n_streams);
+	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFmThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
 			   fmdev_stride, eb, wmax, flag_eps);
 	// one-wave workgroups: the kernel normally has nothing to do, and a 256-thread workgroup waits until a CU has four
 	// wave slots and their registers free at once -- up to a millisecond on the stream that sets the batch period

@@ -16,14 +16,29 @@ constexpr int kTailBytes = 112;                 // raw bytes of history carried 
                                                 // the previous decimated sample the discriminator needs, 16-byte multiple
 constexpr int kNSlots = TFREC_AMD_NSLOTS;
 
-// ---- front-end tile geometry
-#ifndef TFREC_AMD_TILE
-#define TFREC_AMD_TILE 1024
+// ---- front-end tile geometry: a 256-thread workgroup per tile, kFrontOut decimated outputs (and 2 * kFrontOut
+// stage-1 outputs) per thread.  8 per thread: the per-wave scalar work (addresses, taps, edge tests) and the 6 raw
+// samples a thread's stage-1 group shares with its neighbour are paid per 8 outputs instead of per 4.
+#ifndef TFREC_AMD_FRONT_OUT
+#define TFREC_AMD_FRONT_OUT 8
 #endif
-constexpr int kTileDec = TFREC_AMD_TILE;             // decimated outputs per workgroup tile (a multiple of 256)
-constexpr int kFrontThreads = kTileDec / 4;          // four outputs per thread
-constexpr int kRawChunks = (kTailBytes + 8 * kTileDec + 16 + 15) / 16;  // 16-byte chunks staged per tile
-constexpr int kY1Count = 2 * kTileDec + 32;          // stage-1 outputs held per channel (need 2*T+24)
+constexpr int kFrontOut = TFREC_AMD_FRONT_OUT;      // stage-2 outputs per thread: 4 or 8
+static_assert(kFrontOut == 4 || kFrontOut == 8, "the trigger-mask packing knows nibbles and bytes");
+constexpr int kFrontThreads = 256;
+constexpr int kTileDec = kFrontThreads * kFrontOut;  // decimated outputs per workgroup tile
+// LDS image of the stage-1 outputs ((I, Q) float pairs, 8 bytes a slot): a thread's group of 2 * kFrontOut slots is
+// followed by kY1Pad pad slots, so that the 16-byte reads and writes of neighbouring lanes (a lane stride of 64 or 128
+// bytes would put every 2nd / 4th lane on the same banks) fall on different banks.
+constexpr int kY1Group = 2 * kFrontOut;
+#ifndef TFREC_AMD_Y1_PAD
+#define TFREC_AMD_Y1_PAD 2
+#endif
+constexpr int kY1Pad = TFREC_AMD_Y1_PAD;
+constexpr int kY1Stride = kY1Group + kY1Pad;
+__host__ __device__ constexpr int y1_phys(int slot) { return slot + kY1Pad * (slot / kY1Group); }
+constexpr int kY1Count = y1_phys(2 * kTileDec + 24) + 8;  // stage-1 outputs held per tile (need 2*T+24)
+// the discriminator pass keeps the 256 x 4 geometry
+constexpr int kFmThreads = 256, kFmTile = 1024;
 
 // Second-stage taps as h / 65536 (exact in fp32): the multiplier of the FMA form of the FIR stages (frontend.hip).
 struct FrontTaps {
