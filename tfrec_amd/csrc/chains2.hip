@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void tfa1_sample(Slicer &f, BitWriter &bw, int k, int
 	}
 	if (f.mark_lvl > f.rssi_i)
 		f.rssi_i = f.mark_lvl;
-	if (dev < f.mark_lvl / 2) {
+	if (dev < (int)((uint32_t)f.mark_lvl >> 1)) {  // mark_lvl / 2 (tfa1.cpp:164): mark_lvl >= 0, it only becomes a larger dev or its own decay
 		if (f.lbi) {
 			const int gap = index - f.lbi;
 			if (gap > 4) {
@@ -1369,17 +1369,44 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void mark_kernel(const uin
 			const int nv = n - 32 * i < 32 ? n - 32 * i : 32;
 			int pI = (int)(int16_t)(A.prevw & 0xffff), pQ = (int)A.prevw >> 16;
 			uint32_t bits = 0;
+			if (__ballot(nv < 32) == 0ull) {
+				// A whole chunk in every lane (all but a window's last): no per-sample guard, the decay computed beside the
+				// compare instead of under a mask, mark_lvl / 2 as a shift (mark_lvl >= 0: it starts at 0 and only ever becomes
+				// a larger dev or its own decay), the bits shifted in by an add-with-carry, and the maximum taken over dev:
+				// max_k mark_k = max(mark_0, max_{k >= 1} dev_k) -- no mark exceeds that, and the largest dev either becomes
+				// the mark or meets one that is no smaller.  13.5 vector instructions per sample instead of 19 + 5 scalar.
+				uint32_t rev = 0;
+				int dmax = -0x7fffffff;
 #pragma unroll
-			for (int k = 0; k < 32; k++) {
-				const int I = (int)(int16_t)(A.w[k] & 0xffff), Q = (int)A.w[k] >> 16;
-				if (k < nv) {
+				for (int k = 0; k < 32; k++) {
+					const int I = (int)(int16_t)(A.w[k] & 0xffff), Q = (int)A.w[k] >> 16;
 					const int dev = fm_dev_nrzs(I, Q, pI, pQ);
-					mark = dev > mark ? dev : tfa1_decay(mark);
-					mx = mark > mx ? mark : mx;
-					bits |= (uint32_t)(dev < mark / 2) << k;
+					const int decayed = tfa1_decay(mark);
+					mark = dev > mark ? dev : decayed;
+					const int half = (int)((uint32_t)mark >> 1);
+					asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rev) : "v"(dev), "v"(half) : "vcc");
+					if (k == 0)
+						mx = mark > mx ? mark : mx;
+					else
+						dmax = dev > dmax ? dev : dmax;
+					pI = I;
+					pQ = Q;
 				}
-				pI = I;
-				pQ = Q;
+				mx = dmax > mx ? dmax : mx;
+				bits = __builtin_bitreverse32(rev);
+			} else {
+#pragma unroll
+				for (int k = 0; k < 32; k++) {
+					const int I = (int)(int16_t)(A.w[k] & 0xffff), Q = (int)A.w[k] >> 16;
+					if (k < nv) {
+						const int dev = fm_dev_nrzs(I, Q, pI, pQ);
+						mark = dev > mark ? dev : tfa1_decay(mark);
+						mx = mark > mx ? mark : mx;
+						bits |= (uint32_t)(dev < mark / 2) << k;
+					}
+					pI = I;
+					pQ = Q;
+				}
 			}
 			if (i >= i0)
 				T.cand[(size_t)s * T.slots + slot0 + i] = bits;
