@@ -215,7 +215,8 @@ typedef struct {
 	uint64_t biquad_repair_slots; /* 32-sample slots the first repair pass ran (a segment has up to 116) */
 	uint64_t whb_respeculated;   /* (stream, submit) pairs whose lane-parallel WHB decision levels did not reproduce the exact
 				        recurrence's decisions and were demodulated again by the exact kernel */
-	uint64_t reserved[1];
+	uint64_t tfa1_scalar_groups; /* 64-step groups of long TFA_1 windows that the lane-per-step slicer left to the scalar
+				        walk (a candidate at a block's first sample, a stale peak-detector piece, > 64 bits) */
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
 /* Layout of the context's pipeline, named by its number of CHAIN streams: 6 = deep (default: the filter stage of submit

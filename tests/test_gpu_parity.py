@@ -453,6 +453,45 @@ def test_bits_mode_every_store_bit_equals_the_oracle(splits):
     assert n_bits > 20000
 
 
+@pytest.mark.parametrize("vec", ["1", "0"])
+def test_cooperative_slicers_step_per_lane_and_scalar_walk_emit_the_same_bits(vec, monkeypatch):
+    """Long windows (tfa1.cpp:150-178, tfa2.cpp:383-411) are sliced by a wave per window: 64 steps at a time with a step per lane
+    (default), or by the scalar walk (TFREC_AMD_TFA1_VEC=0 / TFREC_AMD_TFA2_VEC=0: what the lane-per-step form falls back to for a
+    group it gives up).  Both must hand decoder::store_bit the oracle's bits, flush by flush -- also across submits that cut
+    the windows (carried last_bit_idx / mark_lvl / thresholds) and through noise above the threshold (one window per stream)."""
+    monkeypatch.setenv("TFREC_AMD_TFA1_VEC", vec)
+    monkeypatch.setenv("TFREC_AMD_TFA2_VEC", vec)
+    n_streams, n_blocks, cut = 6, 36, 12
+    iq = synth.gen_batch(47, 11, n_streams, n_blocks)
+    noisy = synth.gen_stream(47, 99, n_blocks, 0x1F, 16 * 256)  # noise sigma 16 LSB: above -t 500, the trigger never drops
+    iq = np.concatenate([iq, noisy[None, :]])
+    n_streams += 1
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=cut, all_flushes=True, bits=True, max_events=1 << 18) as r:
+        evs = []
+        for k in range(n_blocks // cut):
+            r.submit(np.ascontiguousarray(iq[:, k * cut * 65536:(k + 1) * cut * 65536]))
+            evs.append(r.drain())
+        ev = np.concatenate(evs)
+        st = r.stats()
+    if vec == "0":
+        assert st["tfa1_scalar_groups"] == 0  # (the counter counts groups the lane-per-step form gave up)
+    n_bits = 0
+    for s in range(n_streams):
+        o = O.Oracle(0x2F, 500, 0, log_bits=True)
+        o.process(iq[s])
+        want = {}
+        for ln in o.bits_text().splitlines():
+            p = ln.split()
+            want.setdefault(int(p[1]), []).append(p[3] if len(p) > 3 else "")
+        got = api.bits_by_flush(ev, s)
+        check_stream(ev, s, o)
+        for slot, recs in want.items():
+            for seq, bits in enumerate(recs):
+                assert got.get((slot, seq), "") == bits, "stream %d slot %d flush %d" % (s, slot, seq)
+                n_bits += len(bits)
+    assert n_bits > 30000
+
+
 def _all_streams_equal(ev, iq, types, thresh, all_flushes=True, wide=0, orc=None):
     """every stream of the batch against the oracle (OpenMP, one receiver per stream): vectorised comparison.
     orc: the oracle's events if they were computed already (one ORC_EVENT_DTYPE array per stream)"""

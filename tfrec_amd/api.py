@@ -59,7 +59,7 @@ class Timings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("biquad_segments", C.c_uint64), ("biquad_unconverged", C.c_uint64), ("biquad_serial", C.c_uint64),
                 ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("biquad_repair_slots", C.c_uint64),
-                ("whb_respeculated", C.c_uint64), ("reserved", C.c_uint64 * 1)]
+                ("whb_respeculated", C.c_uint64), ("tfa1_scalar_groups", C.c_uint64)]
 
 
 class FmStats(C.Structure):
@@ -279,7 +279,7 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in Stats._fields_[:7]}
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_}
 
 
 def fm_dev_nrzs_probe(records: np.ndarray, device: int = 0) -> np.ndarray:

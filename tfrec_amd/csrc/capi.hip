@@ -615,6 +615,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.whbscr = c->d_whbscr;
 			T.whbpub = nullptr;
 			T.whb_test_perturb = c->whb_test_perturb;
+			T.tfa1_vec = !(getenv("TFREC_AMD_TFA1_VEC") && atoi(getenv("TFREC_AMD_TFA1_VEC")) == 0);
+			T.tfa2_vec = !(getenv("TFREC_AMD_TFA2_VEC") && atoi(getenv("TFREC_AMD_TFA2_VEC")) == 0);
 			T.whb_force_fail = c->whb_force_fail;
 			T.whbx = c->d_whbx;
 			T.timeout_carry = c->d_tcarry;
@@ -885,6 +887,14 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 				       c->cfg.n_streams, n_blocks, c->sample_base, c->launch, c->win[set], c->d_ld16[set],
 				       c->d_dev32[set], c->d_events[set], c->d_eb[set], c->cfg.flags));
 	}
+#ifdef TFREC_AMD_VECSTAT
+	if (c->submit_seq == 3) {
+		(void)hipDeviceSynchronize();
+		unsigned long long st[16] = { 0 };
+		(void)hipMemcpy(st, c->win[set].stats, sizeof(st), hipMemcpyDeviceToHost);
+		fprintf(stderr, "VECSTAT (one submit) TFA_1: groups %llu, stale piece %llu, entered-with-none hazard %llu, > 64 bits in a lane %llu, lanes with 32 ones or more %llu; TFA_2 family: groups %llu, entered with relative 0 %llu, > 16 rounds %llu, > 64 bits in a lane %llu, walks of the groups that converged %llu\n", st[8], st[9], st[10], st[11], st[5], st[12], st[13], st[14], st[15], st[6]);
+	}
+#endif
 #ifdef TFREC_AMD_COOPSTAT
 	if (c->submit_seq == 3) {
 		(void)hipDeviceSynchronize();

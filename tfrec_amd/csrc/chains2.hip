@@ -1484,9 +1484,53 @@ struct CoopBits {
 	}
 };
 
+// Join the bits the 64 lanes of a wave produced (lane l: `cnt` <= 64 bits in `acc`, LSB first; lane order = bit order) and append
+// them to the wave-uniform writer: prefix sum of the counts, an LDS image of the output words from the writer's pending word
+// on (three ORs per lane), whole words stored by all lanes, the rest becomes the writer's pending word.  One-wave workgroups.
+constexpr int kCoopStageWords = 136;  // 31 carried bits + 64 lanes * 64 bits, + the reach of a lane's three ORs
+__device__ __forceinline__ void coop_join_bits(CoopBits &bw, uint32_t *__restrict__ stage, unsigned long long acc, int cnt)
+{
+	const int lane = threadIdx.x;
+	int incl = cnt;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(incl, o, 64);
+		incl += lane >= o ? t : 0;
+	}
+	const int total = __builtin_amdgcn_readlane(incl, 63);
+	if (total == 0)
+		return;
+	const int nacc = bw.nacc;
+	for (int i = lane; i < kCoopStageWords; i += 64)
+		stage[i] = (i == 0) ? (uint32_t)bw.acc : 0u;
+	__syncthreads();
+	if (cnt > 0) {
+		const int pos = nacc + incl - cnt;
+		const int sh = pos & 31, w0 = pos >> 5;
+		const unsigned long long lo = acc << sh;
+		const uint32_t hi = sh ? (uint32_t)(acc >> (64 - sh)) : 0u;
+		if ((uint32_t)lo)
+			atomicOr(&stage[w0], (uint32_t)lo);
+		if ((uint32_t)(lo >> 32))
+			atomicOr(&stage[w0 + 1], (uint32_t)(lo >> 32));
+		if (hi)
+			atomicOr(&stage[w0 + 2], hi);
+	}
+	__syncthreads();
+	const int nw = (nacc + total) >> 5;  // completed words
+	uint32_t *out = bw.base + ((bw.n - nacc) >> 5);
+	for (int i = lane; i < nw; i += 64)
+		out[i] = stage[i];
+	const uint32_t pend = stage[nw];
+	__syncthreads();
+	bw.acc = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+	bw.nacc = (nacc + total) & 31;
+	bw.n += total;
+}
+
 __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					  size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
-					  const WinTables &T, bool fresh = false, int fresh_lbi = 0)
+					  const WinTables &T, uint32_t *__restrict__ stage, bool fresh = false, int fresh_lbi = 0)
 {
 	const int lane = threadIdx.x;
 	const int a = c / n_streams, s = c - a * n_streams;
@@ -1642,10 +1686,11 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 			}
 		}
 	};
-	In4 nxt4 = load4(g1);
-	for (int gb4 = g1; gb4 <= last; gb4 += 256) {
+	auto old_range = [&](const int ga, const int gz) {  // the stretches of 256 samples from ga on, below gz
+	In4 nxt4 = load4(ga);
+	for (int gb4 = ga; gb4 < gz && gb4 <= last; gb4 += 256) {
 	const In4 cur4 = nxt4;
-	if (gb4 + 256 <= last)
+	if (gb4 + 256 < gz && gb4 + 256 <= last)
 		nxt4 = load4(gb4 + 256);
 	// A whole stretch of 256 samples with frozen thresholds inside the window and inside one block: the eight ballots first,
 	// then step by step -- a step without a sample that could flip last_bit (one in two) costs a scalar select and a
@@ -1771,6 +1816,200 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		}
 	}
 	}
+	};
+	// ---- 64 steps (4096 samples) at a time with a STEP PER LANE, once the thresholds are frozen (round 5).  A lane walks the
+	// candidates of its own step exactly as walk_one_block does -- in ABSOLUTE index units, where demodulator::start's rebase
+	// (decoder.cpp:118-122) is the identity unless last_bit_idx is block-relative 0 when a block begins: a value set at a
+	// block's first sample and still standing 8192 samples later.  A group is shorter than a block, so that can only be the
+	// value a group is ENTERED with (then it is left to the scalar walk); a value set at a block's first sample inside the
+	// group leaves it as the relative 0 it is -- from a start state (last_bit, last_bit_idx) that is first SPECULATED: last_bit = the
+	// polarity of the nearest sample beyond a threshold before the lane, last_bit_idx = the nearest alternation of polarity
+	// before it -- what the state is if every edge before the lane was accepted (96 % of the edges are).  Then every lane's
+	// start state is compared with what the lane before it really left behind; the lanes that were wrong get the true
+	// value and walk again, until nothing changes (lane 0 starts from the true state, so by induction every lane then did;
+	// more than 16 rounds, more than 64 bits in a lane: the group is left to the scalar walk).  ~2 walks of ~200 vector
+	// instructions per 64 steps instead of 64 x (51 scalar instructions per accepted edge + the step's own ~25).
+	auto group_vec = [&](const int gs) -> bool {
+		int lb = lbi, cb = cur_block;
+		if ((gs >> 13) != cb) {
+			lb = rebase_lbi(lb, cb, gs >> 13);
+			cb = gs >> 13;
+		}
+#ifdef TFREC_AMD_VECSTAT
+		if (lane == 0) {
+			atomicAdd(&T.stats[12], 1ull);
+			if (lb == 0)
+				atomicAdd(&T.stats[13], 1ull);
+		}
+#endif
+		if (lb == 0)
+			return false;  // (block-relative 0 is the reference's "no rebase" value)
+		const int Labs = lb + kIndexSpan * cb;
+		const int ng = ((last - gs) >> 6) + 1 < 64 ? ((last - gs) >> 6) + 1 : 64;
+		const int gl = gs + 64 * lane;
+		const int Ibase = 2 * gl;
+		// ---- the step's samples against the thresholds: 64-bit masks, bit k = sample gl + k
+		unsigned long long mH = 0ull, mL = 0ull;
+		if (gl <= last) {
+			const uint4 *src = reinterpret_cast<const uint4 *>(ldrow + (gl - og));
+			uint4 v[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+				v[q] = gl + 8 * q <= last ? src[q] : make_uint4(0u, 0u, 0u, 0u);
+			uint32_t rh[2] = { 0u, 0u }, rl[2] = { 0u, 0u };
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const uint32_t d4[4] = { v[q].x, v[q].y, v[q].z, v[q].w };
+#pragma unroll
+				for (int e = 0; e < 4; e++) {
+					const int s0 = (int)(int16_t)(d4[e] & 0xffffu), s1 = (int)d4[e] >> 16;
+					// (bits shifted in by an add-with-carry: the word comes out bit-reversed)
+					asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rh[q >> 2]) : "v"(s0), "v"(hi) : "vcc");
+					asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rl[q >> 2]) : "v"(s0), "v"(lo) : "vcc");
+					asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rh[q >> 2]) : "v"(s1), "v"(hi) : "vcc");
+					asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rl[q >> 2]) : "v"(s1), "v"(lo) : "vcc");
+				}
+			}
+			mH = (unsigned long long)__builtin_bitreverse32(rh[0]) | ((unsigned long long)__builtin_bitreverse32(rh[1]) << 32);
+			mL = (unsigned long long)__builtin_bitreverse32(rl[0]) | ((unsigned long long)__builtin_bitreverse32(rl[1]) << 32);
+			const int nv = last - gl + 1;
+			if (nv < 64) {
+				const unsigned long long vm = (1ull << nv) - 1ull;
+				mH &= vm;
+				mL &= vm;
+			}
+			mL &= ~mH;
+		}
+		// ---- speculated start states
+		const unsigned long long anym = mH | mL;
+		int sb_, sl_;
+		{
+			const int th = mH ? 63 - (int)__builtin_clzll(mH) : -1, tl = mL ? 63 - (int)__builtin_clzll(mL) : -1;
+			const unsigned long long gen = __ballot(anym != 0ull && th > tl), prop = __ballot(anym == 0ull);
+			const unsigned long long cinm = ((gen | prop) + gen + (unsigned long long)last_bit) ^ prop;
+			sb_ = (int)((cinm >> lane) & 1ull);
+			// the lane's alternations if every one is accepted: the polarity before every bit is a carry chain
+			const unsigned long long sum = (mH | ~anym) + mH + (unsigned long long)sb_;
+			const unsigned long long before = sum ^ ~anym;
+			const unsigned long long edges = (mH & ~before) | (mL & before);
+			const int myedge = Ibase + 2 * (63 - (int)__builtin_clzll(edges | 1ull));
+			const unsigned long long he = __ballot(edges != 0ull);
+			const unsigned long long below = he & ((1ull << lane) - 1ull);
+			const int from = below ? 63 - (int)__builtin_clzll(below) : 0;
+			const int got = __shfl(myedge, from, 64);
+			sl_ = below ? got : Labs;
+		}
+		// ---- walk, compare, walk again
+		unsigned long long acc = 0ull;
+		int cnt = 0, bc = 0, lb_out = sb_, l_out = sl_;
+		bool bad = false, dirty = true;
+		const int acc_lo = td_lo > 9 ? td_lo : 9;
+		const uint32_t acc_span = (uint32_t)(td_hi - acc_lo);
+		int rounds = 0;
+		while (true) {
+			if (dirty) {
+				acc = 0ull;
+				cnt = 0;
+				bc = 0;
+				bad = false;
+				int lbv = sb_, lv = sl_;
+				unsigned long long todo = ~0ull;
+				while (true) {
+					const unsigned long long m = (lbv ? mL : mH) & todo;
+					if (!m)
+						break;
+					const int k = __builtin_ctzll(m);
+					todo = ~1ull << k;
+					const int index = Ibase + 2 * k, d = index - lv;
+					lv = d > 2 ? index : lv;  // tfa2.cpp:410-411 (d was taken first: the edge's timing uses the old value)
+					bc += d > 8 ? 1 : 0;  // tfa2.cpp:391-392
+					if ((uint32_t)(d - acc_lo) <= acc_span) {
+						const int numbits = tfa2_numbits_mul(d, nb_mul);
+						const int run = (numbits < 32 && numbits > 1) ? numbits - 1 : 0;
+						if (cnt + run + 1 > 64) {
+							bad = true;
+						} else {
+							acc |= (unsigned long long)((1u << run) - (uint32_t)lbv) << cnt;
+							cnt += run + 1;
+						}
+						lbv ^= 1;
+						continue;
+					}
+					// not accepted: the run of candidates of the same polarity right behind it only moves last_bit_idx
+					const unsigned long long rest = m >> 1 >> k;
+					const int R = __builtin_ctzll(~rest);
+					if (R > 0) {
+						const int e = index + 2 - lv;
+						const int t_set = e > 2 ? 1 : ((2 - e) >> 1) + 2;
+						if (t_set <= R)
+							lv = index + 2 * (t_set + 2 * ((R - t_set) >> 1));
+						todo = ~1ull << (k + R);
+					}
+				}
+				lb_out = lbv;
+				l_out = lv;
+			}
+			// what the lane before left behind (lane 0: the state the group was entered with)
+			int pb = __shfl_up(lb_out, 1, 64), pl = __shfl_up(l_out, 1, 64);
+			if (lane == 0) {
+				pb = last_bit;
+				pl = Labs;
+			}
+			dirty = pb != sb_ || pl != sl_;
+			sb_ = pb;
+			sl_ = pl;
+			if (__ballot(dirty) == 0ull)
+				break;
+			if (++rounds > 16) {
+#ifdef TFREC_AMD_VECSTAT
+				if (lane == 0)
+					atomicAdd(&T.stats[14], 1ull);
+#endif
+				return false;
+			}
+		}
+#ifdef TFREC_AMD_VECSTAT
+		{
+			const bool anybad = __ballot(bad) != 0ull;
+			if (lane == 0) {
+				atomicAdd(&T.stats[6], (unsigned long long)(rounds + 1));
+				atomicAdd(&T.stats[15], anybad ? 1ull : 0ull);
+			}
+		}
+#endif
+		if (__ballot(bad) != 0ull)
+			return false;
+		coop_join_bits(bw, stage, acc, cnt);
+		// ---- commit the group
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1)
+			bc += __shfl_xor(bc, o, 64);
+		bitcnt += bc;
+		last_bit = __builtin_amdgcn_readlane(lb_out, 63);
+		const int Lnew = __builtin_amdgcn_readlane(l_out, 63);
+		const int gend = gs + 64 * ng - 1 < last ? gs + 64 * ng - 1 : last;
+		cur_block = gend >> 13;
+		lbi = Lnew - kIndexSpan * cur_block;
+		return true;
+	};
+	if (!(stage && T.tfa2_vec && nb_mul)) {
+		old_range(g1, last + 1);
+	} else {
+		for (int pos = g1; pos <= last;) {
+			if (bitcnt >= 10) {
+				if (!group_vec(pos)) {
+#ifndef TFREC_AMD_COOPSTAT
+					atomicAdd(&T.stats[7], lane == 0 ? (1ull << 32) : 0ull);  // (high half: TFA_2-family groups left to the scalar walk)
+#endif
+					old_range(pos, pos + 4096);
+				}
+				pos += 4096;
+			} else {  // the thresholds still adapt (a head that gave up): stretch by stretch
+				old_range(pos, pos + 256);
+				pos += 256;
+			}
+		}
+	}
 	const int bl = last >> 13;
 	if (bl != cur_block) {
 		lbi = rebase_lbi(lbi, cur_block, bl);
@@ -1808,8 +2047,31 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 	}
 }
 
+// TFA_1, 64 steps (4096 samples) at a time with a STEP PER LANE (round 5).  The scalar walk further down spends ~55 scalar
+// instructions on every run of candidates and ~60 on every step (2.0 M runs in 2.2 M steps per benchmark batch: the most
+// expensive code of the batch after the TFA_2 walk).  What makes the lane-parallel form exact:
+//   * In ABSOLUTE index units I = 2 * (sample of the submit) demodulator::start's rebase (decoder.cpp:118-122) is the identity
+//     for every value but a block-relative 0, which can only come about when a candidate at a block's first sample sets it
+//     (tfa1.cpp:175-176 with index 0) and which the demodulator reads as "no pulse yet" (:165).  So: an absolute value at a
+//     block's first sample (a multiple of 16384) means "none" -- the next run's first sample emits nothing -- and everything
+//     else is plain arithmetic.  (Within the run that set it the relative 0 is also the true relative index: the closed
+//     forms hold.)  Only a group that is ENTERED with "none" and has a candidate at a block's second sample (index 2:
+//     "index - 0 > 2" does not fire, the value stays "none") is left to the scalar walk.
+//   * A maximal run of candidates that begins at I0 behind a non-candidate finds I0 - lbi >= 4: the rule "index - lbi > 2"
+//     sets lbi = I0 whatever lbi was, so what the run leaves behind (I0 + 4 * ((len - 1) >> 1)) does not depend on history;
+//     only the bits its FIRST sample emits do (the gap to what the run before it left behind: tfa1.cpp:167-173).
+//   * A run that crosses a step boundary continues in the next lane with I0 - lbi = 2 or 4, 2 iff the run has had an odd number
+//     of samples so far (by the same closed form the scalar walk uses for the rest of a run): a parity, generated by every
+//     lane whose word ends in an odd number of ones, handed through words that are all ones -- the carries of ONE 64-bit
+//     addition of two ballots.
+// So: every lane walks the runs of its own 64-bit candidate word with the scalar walk's formulas (a lane's first run
+// either continues the lane before it, or it is a maximal run's beginning and only its emission waits for the value the
+// nearest lane with candidates before it leaves behind); the lanes' bits (at most 64 each, else the group is left to the
+// scalar walk) are joined by a prefix sum through an LDS image of the output words.  ~400 instructions per 64 steps
+// instead of ~7000.  mark_kernel's pieces (16 steps each) are checked for the whole group first.
 __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
-					  size_t dec_stride, const ChainLaunch &L, const WinTables &T, int *__restrict__ lds_m)
+					  size_t dec_stride, const ChainLaunch &L, const WinTables &T, int *__restrict__ lds_m,
+					  uint32_t *__restrict__ stage)
 {
 	const int lane = threadIdx.x;
 	const int a = c / n_streams, s = c - a * n_streams;
@@ -1842,96 +2104,252 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 	const int slot0 = win_slot0(og, j);
 	const uint32_t *candrow = T.cand + (size_t)s * T.slots + slot0;
 	const MarkPiece *markrow = T.mark + (size_t)s * T.slots + slot0;
-	bool piece_ok = false;
-	MarkPiece mp = { 0, 0, 0, 0 };
-	// the candidate words of 64 steps at a time, a step per lane (fetched per step they were two scalar loads the wave
-	// waited for in every step)
-	uint32_t cw_lo = 0, cw_hi = 0;
-	for (int gb = og; gb <= last; gb += 64) {
-		const int step = (gb - og) >> 6;  // two slots per step, kMarkSlots / 2 steps per piece
-		if ((step & 63) == 0) {
-			const int sl = step + lane;
-			const bool in = og + 64 * sl <= last;
-			cw_lo = in ? candrow[2 * sl] : 0u;
-			cw_hi = in ? candrow[2 * sl + 1] : 0u;
-		}
-		if ((step & (kMarkSlots / 2 - 1)) == 0) {
-			mp = markrow[2 * step];
-			piece_ok = mp.start == mark;
-			if (piece_ok && mp.max > rssi_lane)
-				rssi_lane = mp.max;  // tfa1.cpp:161-162
-		}
-		const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
-		unsigned long long m;
-		if (piece_ok) {
-			const unsigned long long lo = (uint32_t)__builtin_amdgcn_readlane((int)cw_lo, step & 63);
-			const unsigned long long hi = nv > 32 ? (uint32_t)__builtin_amdgcn_readlane((int)cw_hi, step & 63) : 0u;
-			m = lo | (hi << 32);
-			if (gb + 64 > last || ((step + 1) & (kMarkSlots / 2 - 1)) == 0)
-				mark = mp.end;  // the piece ends with this step
-		} else {
-			const uint2 cur = load(gb + lane <= last ? gb + lane : last);
-			const int dev = fm_dev_nrzs((int)(int16_t)(cur.x & 0xffff), (int)cur.x >> 16, (int)(int16_t)(cur.y & 0xffff),
-						    (int)cur.y >> 16);
-			// the peak detector, wave-uniform (tfa1.cpp:157-160); mark >= 0 always, so (int) truncation is exact
-			for (int k = 0; k < nv; k++) {
-				const int dk = __builtin_amdgcn_readlane(dev, k);
-				mark = dk > mark ? dk : tfa1_decay(mark);
-				lds_m[k] = mark;
-			}
-			__syncthreads();
-			const int mk = lds_m[lane];
-			__syncthreads();
-			const bool valid = lane < nv;
-			if (valid && mk > rssi_lane)
-				rssi_lane = mk;  // tfa1.cpp:161-162
-			m = __ballot(valid && dev < mk / 2);  // tfa1.cpp:164
-			atomicAdd(&T.stats[4], lane == 0 ? 1ull : 0ull);  // steps recomputed (tfrec_amd_get_stats)
-		}
-#ifdef TFREC_AMD_COOPSTAT
-		if (lane == 0)
-			atomicAdd(&T.stats[11], 1ull);
-#endif
-		while (m) {
-#ifdef TFREC_AMD_COOPSTAT
-			if (lane == 0)
-				atomicAdd(&T.stats[12], 1ull);
-#endif
-			const int k0 = __builtin_ctzll(m);
-			const unsigned long long inv = ~(m >> k0);
-			int len = inv ? __builtin_ctzll(inv) : 64 - k0;  // run of consecutive candidates
-			const int g0 = gb + k0;
-			const int left_in_block = kBlockDec - (g0 & (kBlockDec - 1));
-			if (len > left_in_block)
-				len = left_in_block;  // last_bit_idx is rebased at every block start: cut the run there
-			m = (k0 + len >= 64) ? 0ull : (m & (~0ull << (k0 + len)));
-			const int b = g0 >> 13;
-			if (b != cur_block) {
-				lbi = rebase_lbi(lbi, cur_block, b);
-				cur_block = b;
-			}
-			const int i0 = 2 * (g0 & (kBlockDec - 1));
-			// first sample of the run: tfa1.cpp:165-177
-			if (lbi) {
-				const int gap = i0 - lbi;
-				if (gap > 4) {
-					const int ones = gap >= 22 ? (gap - 22) / 20 + 1 : 0;  // ones for n = 22, 42, ... <= gap
-					if (ones < 32) {
-						bw.put_bits((1u << ones) - 1u, ones + 1);  // ... and the zero behind them, in one go
-					} else {
-						bw.put_run(1, ones);
-						bw.put_run(0, 1);
-					}
+	const int nsteps = ((last - og) >> 6) + 1;
+	const bool use_vec = T.tfa1_vec != 0;
+	for (int sb = 0; sb < nsteps; sb += 64) {
+		// the candidate words of 64 steps at a time, a step per lane (fetched per step they were two scalar loads the wave
+		// waited for in every step); bits behind the window's last sample are zero (mark_kernel), a half it did not write is not read
+		const int sl = sb + lane;
+		const int gb_l = og + 64 * sl;
+		const uint32_t cw_lo = gb_l <= last ? candrow[2 * sl] : 0u;
+		const uint32_t cw_hi = gb_l + 32 <= last ? candrow[2 * sl + 1] : 0u;
+		const int ng = nsteps - sb < 64 ? nsteps - sb : 64;
+		bool done = false;
+		if (use_vec) {
+			// ---- the group's pieces: each must have started from the true value
+			const int np = (ng + kMarkSlots / 2 - 1) / (kMarkSlots / 2);
+			MarkPiece mpl = { 0, 0, 0, 0 };
+			if (lane < np)
+				mpl = markrow[2 * (sb + (kMarkSlots / 2) * lane)];
+			int mk = mark, rmax = 0;
+			bool ok = true;
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				if (p < np) {
+					ok = ok && __builtin_amdgcn_readlane(mpl.start, p) == mk;
+					mk = __builtin_amdgcn_readlane(mpl.end, p);
+					const int mx_ = __builtin_amdgcn_readlane(mpl.max, p);
+					rmax = mx_ > rmax ? mx_ : rmax;
 				}
 			}
-			if (i0 - lbi > 2)
-				lbi = i0;
-			// the rest of the run: every gap is <= 4, so nothing is emitted; last_bit_idx follows "index - lbi > 2"
-			if (len > 1) {
-				const int d = i0 - lbi;               // 0 (just set) or 2
-				const int t1 = d >= 2 ? 1 : 2;        // first t >= 1 with i0 + 2t - lbi > 2
-				if (t1 <= len - 1)
-					lbi = i0 + 2 * t1 + 4 * ((len - 1 - t1) >> 1);
+			const unsigned long long w = (unsigned long long)cw_lo | ((unsigned long long)cw_hi << 32);
+			const bool have = lbi != 0;
+			const int Labs = have ? lbi + kIndexSpan * cur_block : kIndexSpan * ((og + 64 * sb) >> 13);  // ("none": a block's first sample)
+			// ---- entered with "none": a candidate at a block's second sample would leave it standing
+			const int rel = gb_l & (kBlockDec - 1);
+			const int d1 = (kBlockDec + 1 - rel) & (kBlockDec - 1);
+			const bool hz = !have && d1 < 64 && ((w >> d1) & 1ull);
+#ifdef TFREC_AMD_VECSTAT
+			{
+				const bool anyhz = __ballot(hz) != 0ull;
+				if (lane == 0) {
+					atomicAdd(&T.stats[8], 1ull);
+					if (!ok)
+						atomicAdd(&T.stats[9], 1ull);
+					else if (anyhz)
+						atomicAdd(&T.stats[10], 1ull);
+				}
+			}
+#endif
+			ok = ok && __ballot(hz) == 0ull;
+			if (ok) {
+				// ---- does a lane's first run continue the lane before it, and with which parity
+				const int Ibase = 2 * gb_l;
+				const int g0 = 2 * (og + 64 * sb) - Labs;  // the group's first sample against last_bit_idx
+				const bool cont0 = have && g0 <= 4 && (__builtin_amdgcn_readlane((int)cw_lo, 0) & 1);
+				const int q = ~w ? (int)__builtin_clzll(~w) : 64;  // ones at the word's top
+				const unsigned long long pm = __ballot(q < 64 && (q & 1)), fm = __ballot(q == 64);
+				const unsigned long long cin = (((pm | fm) + pm + ((cont0 && g0 == 2) ? 1ull : 0ull)) ^ fm);
+				const int up = __shfl_up((int)(cw_hi >> 31), 1, 64);
+				const bool cont_l = lane == 0 ? cont0 : ((cw_lo & 1u) && up);
+				int Lc = Ibase - (((cin >> lane) & 1ull) ? 2 : 4);  // (a continued run's last_bit_idx; else set below)
+				unsigned long long ww = w, acc = 0ull;
+				int cnt = 0, I0f = 0;
+				bool bad = false, defer = false, first = true;
+				while (__ballot(ww != 0ull) != 0ull) {
+					if (ww != 0ull) {
+						const int k0 = __builtin_ctzll(ww);
+						const unsigned long long inv = ~(ww >> k0);
+						const int len = inv ? __builtin_ctzll(inv) : 64 - k0;  // run of consecutive candidates
+						ww = (k0 + len >= 64) ? 0ull : (ww & (~0ull << (k0 + len)));
+						const int I0 = Ibase + 2 * k0;
+						if (first && !cont_l) {  // a maximal run begins: gap >= 4, lbi = I0; its bits wait for the gap
+							defer = true;
+							I0f = I0;
+							Lc = I0;
+						} else {  // first sample of the run: tfa1.cpp:165-177
+							const int gap = I0 - Lc;
+							if (gap > 4 && (Lc & (kIndexSpan - 1)) != 0) {  // (tfa1.cpp:165: a block-relative 0 is "no pulse yet")
+								const int ones = gap >= 22 ? (gap - 22) / 20 + 1 : 0;  // ones for n = 22, 42, ... <= gap
+								if (ones >= 32 || cnt + ones + 1 > 64) {
+									bad = true;
+								} else {
+									acc |= ((1ull << ones) - 1ull) << cnt;  // ... and the zero behind them
+									cnt += ones + 1;
+								}
+							}
+							if (gap > 2)
+								Lc = I0;
+						}
+						first = false;
+						// the rest of the run: every gap is <= 4, so nothing is emitted; last_bit_idx follows "index - lbi > 2"
+						if (len > 1) {
+							const int d = I0 - Lc;          // 0 (just set) or 2
+							const int t1 = d >= 2 ? 1 : 2;  // first t >= 1 with I0 + 2t - lbi > 2
+							if (t1 <= len - 1)
+								Lc = I0 + 2 * t1 + 4 * ((len - 1 - t1) >> 1);
+						}
+					}
+				}
+				// ---- the deferred first runs: the gap to what the nearest lane with candidates before leaves behind
+				const unsigned long long ne = __ballot(w != 0ull);
+				const unsigned long long below = ne & ((1ull << lane) - 1ull);
+				const int src = below ? 63 - (int)__builtin_clzll(below) : 0;
+				const int Lsrc = __shfl(Lc, src, 64);
+				const int Lprev = below ? Lsrc : Labs;
+				// (A lane's LATER runs lie within 64 samples of the one before: at most 6 ones.  Its first run can come after any
+				// silence -- another protocol's burst holds the deviation up for thousands of samples --: 32 ones or more go through
+				// the wave-uniform writer, between the lanes before and this lane's other bits.)
+				int ones_long = 0;
+				if (defer && (Lprev & (kIndexSpan - 1)) != 0) {
+					const int gap = I0f - Lprev;
+					if (gap <= 2)
+						bad = true;  // (cannot happen: see above)
+					if (gap > 4) {
+						const int ones = gap >= 22 ? (gap - 22) / 20 + 1 : 0;
+						if (ones >= 32) {
+							ones_long = ones;
+						} else if (cnt + ones + 1 > 64) {
+							bad = true;
+						} else {
+							acc = (acc << (ones + 1)) | ((1ull << ones) - 1ull);  // they come before the lane's other bits
+							cnt += ones + 1;
+						}
+					}
+				}
+#ifdef TFREC_AMD_VECSTAT
+				{
+					const bool anybad = __ballot(bad) != 0ull;
+					const unsigned long long nlong = (unsigned long long)__builtin_popcountll(__ballot(ones_long != 0));
+					if (lane == 0) {
+						atomicAdd(&T.stats[11], anybad ? 1ull : 0ull);
+						atomicAdd(&T.stats[5], nlong);
+					}
+				}
+#endif
+				if (__ballot(bad) == 0ull) {
+					unsigned long long longs = __ballot(ones_long != 0);
+					for (int from = 0;;) {
+						const int to = longs ? (int)__builtin_ctzll(longs) : 64;
+						const bool mine = lane >= from && lane < to;
+						coop_join_bits(bw, stage, mine ? acc : 0ull, mine ? cnt : 0);
+						if (to == 64)
+							break;
+						bw.put_run(1, __builtin_amdgcn_readlane(ones_long, to));
+						bw.put_run(0, 1);
+						longs &= longs - 1ull;
+						from = to;
+					}
+					// ---- commit the group
+					mark = mk;
+					rssi_lane = rmax > rssi_lane ? rmax : rssi_lane;
+					const int gend = og + 64 * (sb + ng) - 1 < last ? og + 64 * (sb + ng) - 1 : last;
+					const int nb = gend >> 13;
+					const int Lnew = ne != 0ull ? __builtin_amdgcn_readlane(Lc, 63 - (int)__builtin_clzll(ne)) : Labs;
+					lbi = (Lnew & (kIndexSpan - 1)) != 0 ? Lnew - kIndexSpan * nb : 0;
+					cur_block = nb;
+					done = true;
+				}
+			}
+		}
+		if (done)
+			continue;
+#ifndef TFREC_AMD_COOPSTAT
+		if (use_vec)
+			atomicAdd(&T.stats[7], lane == 0 ? 1ull : 0ull);  // groups left to the scalar walk (tfrec_amd_get_stats)
+#endif
+		bool piece_ok = false;
+		MarkPiece mp = { 0, 0, 0, 0 };
+		for (int step = sb; step < sb + ng; step++) {
+			const int gb = og + 64 * step;
+			if ((step & (kMarkSlots / 2 - 1)) == 0) {
+				mp = markrow[2 * step];
+				piece_ok = mp.start == mark;
+				if (piece_ok && mp.max > rssi_lane)
+					rssi_lane = mp.max;  // tfa1.cpp:161-162
+			}
+			const int nv = last - gb + 1 < 64 ? last - gb + 1 : 64;
+			unsigned long long m;
+			if (piece_ok) {
+				const unsigned long long lo = (uint32_t)__builtin_amdgcn_readlane((int)cw_lo, step & 63);
+				const unsigned long long hi = (uint32_t)__builtin_amdgcn_readlane((int)cw_hi, step & 63);
+				m = lo | (hi << 32);
+				if (gb + 64 > last || ((step + 1) & (kMarkSlots / 2 - 1)) == 0)
+					mark = mp.end;  // the piece ends with this step
+			} else {
+				const uint2 cur = load(gb + lane <= last ? gb + lane : last);
+				const int dev = fm_dev_nrzs((int)(int16_t)(cur.x & 0xffff), (int)cur.x >> 16, (int)(int16_t)(cur.y & 0xffff),
+							    (int)cur.y >> 16);
+				// the peak detector, wave-uniform (tfa1.cpp:157-160); mark >= 0 always, so (int) truncation is exact
+				for (int k = 0; k < nv; k++) {
+					const int dk = __builtin_amdgcn_readlane(dev, k);
+					mark = dk > mark ? dk : tfa1_decay(mark);
+					lds_m[k] = mark;
+				}
+				__syncthreads();
+				const int mk = lds_m[lane];
+				__syncthreads();
+				const bool valid = lane < nv;
+				if (valid && mk > rssi_lane)
+					rssi_lane = mk;  // tfa1.cpp:161-162
+				m = __ballot(valid && dev < mk / 2);  // tfa1.cpp:164
+				atomicAdd(&T.stats[4], lane == 0 ? 1ull : 0ull);  // steps recomputed (tfrec_amd_get_stats)
+			}
+#ifdef TFREC_AMD_COOPSTAT
+			if (lane == 0)
+				atomicAdd(&T.stats[11], 1ull);
+#endif
+			while (m) {
+#ifdef TFREC_AMD_COOPSTAT
+				if (lane == 0)
+					atomicAdd(&T.stats[12], 1ull);
+#endif
+				const int k0 = __builtin_ctzll(m);
+				const unsigned long long inv = ~(m >> k0);
+				int len = inv ? __builtin_ctzll(inv) : 64 - k0;  // run of consecutive candidates
+				const int g0 = gb + k0;
+				const int left_in_block = kBlockDec - (g0 & (kBlockDec - 1));
+				if (len > left_in_block)
+					len = left_in_block;  // last_bit_idx is rebased at every block start: cut the run there
+				m = (k0 + len >= 64) ? 0ull : (m & (~0ull << (k0 + len)));
+				const int b = g0 >> 13;
+				if (b != cur_block) {
+					lbi = rebase_lbi(lbi, cur_block, b);
+					cur_block = b;
+				}
+				const int i0 = 2 * (g0 & (kBlockDec - 1));
+				// first sample of the run: tfa1.cpp:165-177
+				if (lbi) {
+					const int gap = i0 - lbi;
+					if (gap > 4) {
+						const int ones = gap >= 22 ? (gap - 22) / 20 + 1 : 0;  // ones for n = 22, 42, ... <= gap
+						if (ones < 32) {
+							bw.put_bits((1u << ones) - 1u, ones + 1);  // ... and the zero behind them, in one go
+						} else {
+							bw.put_run(1, ones);
+							bw.put_run(0, 1);
+						}
+					}
+				}
+				if (i0 - lbi > 2)
+					lbi = i0;
+				// the rest of the run: every gap is <= 4, so nothing is emitted; last_bit_idx follows "index - lbi > 2"
+				if (len > 1) {
+					const int d = i0 - lbi;               // 0 (just set) or 2
+					const int t1 = d >= 2 ? 1 : 2;        // first t >= 1 with i0 + 2t - lbi > 2
+					if (t1 <= len - 1)
+						lbi = i0 + 2 * t1 + 4 * ((len - 1 - t1) >> 1);
+				}
 			}
 		}
 	}
@@ -1971,6 +2389,7 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 							 ChainLaunch L, WinTables T, int kind)
 {
 	__shared__ int lds_m[64];
+	__shared__ uint32_t t1_stage[kCoopStageWords];
 	latency_prio();
 	const int M = n_blocks * kBlockDec;
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
@@ -1980,9 +2399,9 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 		const uint2 it = T.items[(size_t)q * total + idx];
 		const int c = __builtin_amdgcn_readfirstlane((int)it.x), j = __builtin_amdgcn_readfirstlane((int)it.y);
 		if (kind == 0)
-			coop_tfa1(c, j, n_streams, M, dec, dec_stride, L, T, lds_m);
+			coop_tfa1(c, j, n_streams, M, dec, dec_stride, L, T, lds_m, t1_stage);
 		else
-			coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T);
+			coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, t1_stage);
 	}
 }
 
@@ -3336,7 +3755,7 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 							      // form never gets here: it deferred the chain above)
 						if (lead)
 							atomicAdd(&T.stats[3], 1ull);
-						coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, true,
+						coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, nullptr, true,
 							  rebase_lbi(lbi, lbi_block, og >> 13));
 						__threadfence();  // lane 0's stores (bits, result) before every lane reads them
 						__syncthreads();

@@ -285,6 +285,8 @@ struct WinTables {
 	// one" becomes "off by at most |D|" in the ambiguity rule and in the check: drives the carry / amb / redo paths of a
 	// window that spans submits with ordinary input.  0 in production (tolerance 1).
 	int32_t whb_test_perturb;
+	int32_t tfa2_vec;            // ... and so does the TFA_2 family's, once a window's thresholds are frozen (TFREC_AMD_TFA2_VEC=0: the scalar walk)
+	int32_t tfa1_vec;            // the cooperative TFA_1 slicer walks 64 steps at a time, a step per lane (TFREC_AMD_TFA1_VEC=0: the scalar walk)
 };
 constexpr int kStatusDead = 0xff;  // tfrec_amd_event::status of a retracted event: never reported
 
