@@ -622,11 +622,14 @@ def main():
                         "issue_busy_ms": vj["issue_roof_ms"],
                         "issue_busy_over_period": round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4),
                         "note": ("NOT a roofline: the sum over the batch's kernels (each measured alone) of SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs "
-                                 "x 2.36 GHz) = wave-quad-cycles with an instruction of any kind in flight = 1.12 x (VALU + SALU wave instructions).  "
-                                 "The batch period has equalled this sum within 1-5 percent for five rounds (DESIGN.md section 3, 'What binds'): "
-                                 "a descriptive law of this implementation's instruction count -- scalar instructions cost like vector ones --, while "
-                                 "no single resource is saturated (memory controllers 32 percent busy, VALU issue 58 percent, clock 2.36 GHz, LDS and "
-                                 "register footprints without effect: profiles/r05_*.txt).  What bounds the path nominally is in `roofline` "
+                                 "x 2.36 GHz) = wave-quad-cycles with an instruction of any kind in flight = ~1.1 x (VALU + SALU wave instructions).  "
+                                 "For four and a half rounds the batch period equalled this sum within 1-5 percent; the lane-per-step cooperative slicers "
+                                 "of round 5 took 0.48 G quad-cycles (14 percent) out of it and the period followed by 3-5 percent only: the sum is a "
+                                 "description of how full the SIMDs are, not a bound -- the period now sits on the two serial per-stream WHB kernels "
+                                 "(whb_demod_kernel<false> 5.0 ms inside the batch on its stream, 2.8 ms alone; whb_verify_kernel 4.6 / 3.1), which "
+                                 "run one wave per SIMD of dependent instructions and stretch beside the other chains whatever their priority "
+                                 "(DESIGN.md section 3, 'What binds').  No single resource is saturated (memory controllers ~1/3 busy, VALU issue "
+                                 "~55 percent, clock 2.36 GHz; profiles/r05_*.txt).  What bounds the path nominally is in `roofline` "
                                  "(hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms); source profile: profiles/" + ptag + "_valu.json"),
                         "source": "profiles/%s_valu.json (builder's rocprofv3 --pmc passes; NOT measured in this run)" % ptag,
                     }

@@ -474,7 +474,7 @@ def test_cooperative_slicers_step_per_lane_and_scalar_walk_emit_the_same_bits(ve
         ev = np.concatenate(evs)
         st = r.stats()
     if vec == "0":
-        assert st["tfa1_scalar_groups"] == 0  # (the counter counts groups the lane-per-step form gave up)
+        assert st["tfa1_scalar_groups"] == 0 and st["tfa2_scalar_groups"] == 0  # (groups the lane-per-step form gave up)
     n_bits = 0
     for s in range(n_streams):
         o = O.Oracle(0x2F, 500, 0, log_bits=True)

@@ -279,7 +279,11 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        return {n: int(getattr(st, n)) for n, _ in Stats._fields_}
+        d = {n: int(getattr(st, n)) for n, _ in Stats._fields_}
+        # (one counter, two halves: groups of 64 steps the lane-per-step cooperative slicers left to their scalar walks)
+        d["tfa2_scalar_groups"] = d["tfa1_scalar_groups"] >> 32
+        d["tfa1_scalar_groups"] &= 0xFFFFFFFF
+        return d
 
 
 def fm_dev_nrzs_probe(records: np.ndarray, device: int = 0) -> np.ndarray:

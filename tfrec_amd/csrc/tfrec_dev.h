@@ -334,10 +334,11 @@ constexpr int kSegSlots = TFREC_AMD_SEG_SLOTS;  // biquad segments: 256 in-windo
                                                 // (profiles/r05_ab_segments.txt): 128 -> 256 with the same number of waves = a quarter fewer repair
                                                 // slots, the batch 2.5 % shorter; 512: no better (the passes stretch), 1024: 17 % worse
 constexpr int kSegConverged = 0x40000000, kSegRan = 0x20000000;
-constexpr int kLongWindow = 4096;  // samples; longer windows go to the wave-cooperative slicers (default).  The
-                                   // lane-per-window slicers cost fewer instructions per sample (64 windows share a
-                                   // wave's instruction stream), the cooperative ones less latency per window: 4096
-                                   // measured 4-8 % better than 2048 once the batch ran close to the VALU issue bound
+constexpr int kLongWindow = 1024;  // samples; longer windows go to the wave-cooperative slicers (default; TFREC_AMD_COOP_MIN).
+                                   // Until round 5 the cooperative slicers were scalar walks (51 scalar instructions per
+                                   // accepted edge) and 4096 measured 4-8 % better than 2048; with a step per lane they cost
+                                   // less per window than a lane of the lane-per-window kernels, whose longest window sets
+                                   // their duration: 1024-2048 measure 1.5 % better than 4096 (profiles/r05_ab_coop_min.txt)
 
 static_assert(sizeof(tfrec_amd_event) == 96, "event ABI is 96 bytes");
 static_assert(offsetof(tfrec_amd_event, rdata) == 32, "event rdata offset");
