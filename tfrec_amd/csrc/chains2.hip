@@ -1424,17 +1424,22 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void mark_kernel(const uin
 }
 
 // ------------------------------------------------------------------------------------------------ K4b
-// Wave-cooperative slicers for LONG windows: one wave per window, lane n owns sample n of a 64-sample step.
+// Wave-cooperative slicers for LONG windows (kLongWindow): one wave per window.
 // A lane-per-window slicer needs ~100 instructions per sample on a serial path; a 40 000-sample burst then
-// takes milliseconds whatever the GPU's width.  Here the per-sample work is done by 64 lanes at once and only
-// the sparse part stays serial (wave-uniform):
-//   TFA_2 family (tfa2.cpp:357-412, after the thresholds froze): the candidate edges are two ballots
-//       (ld > hi, ld < lo); the walk visits only the candidates of the polarity that can flip last_bit.
-//   TFA_1 (tfa1.cpp:150-178): the peak detector mark_lvl = dev > mark_lvl ? dev : (int)(mark_lvl*0.95) is a
-//       64-step uniform recurrence (6 instructions per sample); "dev < mark_lvl/2" is a ballot, and the walk
-//       handles each RUN of consecutive candidates in O(1): only the first sample of a run can emit bits (later
-//       gaps are <= 4), the others move last_bit_idx forward by 4 every second sample.
-// Bits are appended by a wave-uniform writer (lane 0 stores).
+// takes milliseconds whatever the GPU's width.  Two forms of the same rules:
+//   * the scalar walks (rounds 2-4): lane n owns sample n of a 64-sample step, the per-sample work is done by 64 lanes at
+//     once and only the sparse part stays serial (wave-uniform) --
+//       TFA_2 family (tfa2.cpp:357-412, after the thresholds froze): the candidate edges are two ballots
+//           (ld > hi, ld < lo); the walk visits only the candidates of the polarity that can flip last_bit.
+//       TFA_1 (tfa1.cpp:150-178): the peak detector mark_lvl = dev > mark_lvl ? dev : (int)(mark_lvl*0.95) is a
+//           64-step uniform recurrence (6 instructions per sample); "dev < mark_lvl/2" is a ballot, and the walk
+//           handles each RUN of consecutive candidates in O(1): only the first sample of a run can emit bits (later
+//           gaps are <= 4), the others move last_bit_idx forward by 4 every second sample.
+//     Bits are appended by a wave-uniform writer (lane 0 stores).  51-55 scalar instructions per edge / run: 0.51 G of the
+//     benchmark batch's 1.14 G scalar instructions;
+//   * a STEP PER LANE (round 5; coop_tfa1 / coop_tfa2's group_vec): 64 steps per pass,
+//     every lane walks the candidates of its own step with the same formulas in absolute index units, the lanes' bits are
+//     joined by coop_join_bits.  The scalar walks are what a group falls back to (0.7 % / 2.6 % of the groups).
 struct CoopBits {
 	uint32_t *base;
 	unsigned long long acc;
