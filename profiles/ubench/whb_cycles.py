@@ -23,13 +23,16 @@ with api.Receiver(ns, mask, 500, 0, max_blocks=nb, max_events=1 << 20) as r:
             r.submit(d); r.drain()
     st = api.Stats()
     r.L.tfrec_amd_get_stats(r.h, C.byref(st))
-    raw = [int(x) for x in (st.tfa1_recomputed, st.biquad_repair_slots, *st.reserved)]
+    raw = [int(x) for x in (st.tfa1_recomputed, st.biquad_repair_slots, st.whb_respeculated, st.tfa1_scalar_groups)]
     span = [int(st.biquad_unconverged), int(st.biquad_serial), int(st.tfa2_resliced)]
 steps, usteps = raw[0] >> 32, raw[0] & 0xffffffff
 print("per stream and submit: steps %.0f, with recurrence %.0f" % (steps / ns / nsub, usteps / ns / nsub))
 print("cycles per stream and submit: recurrence %.2fM, whole demodulator %.2fM; wall %.3f ms per stream -> shader clock %.2f GHz" % (
     raw[1] / ns / nsub / 1e6, raw[3] / ns / nsub / 1e6, raw[2] / ns / nsub / 1e5, raw[3] / max(raw[2], 1) / 10.0))
 print("recurrence: %.0f cycles per step = %.1f per sample" % (raw[1] / max(usteps, 1), raw[1] / max(usteps, 1) / 64))
+if not (len(sys.argv) > 3 and sys.argv[3] == "span"):
+    print("cycles per step (all steps): loop top -> recurrence %.0f, recurrence (steps with it) %.0f, candidates %.0f, state update + loop end %.0f; whole kernel / steps %.0f" % (
+        span[0] / max(steps, 1), raw[1] / max(usteps, 1), span[1] / max(steps, 1), span[2] / max(steps, 1), raw[3] / max(steps, 1)))
 if len(sys.argv) > 3 and sys.argv[3] == "span":  # library built with -DTFREC_AMD_PROFILE_WHB_SPAN as well
     first = (~span[0]) & 0xFFFFFFFFFFFFFFFF
     mean = (int(st.biquad_segments) - ns * (first & 0xffffffffff)) / ns  # (low 40 bits summed)
