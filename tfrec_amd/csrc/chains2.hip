@@ -405,13 +405,11 @@ struct ChunkIter {
 // trajectory after a few hundred samples, and once the full state (yn, yn1 + the two last inputs) matches
 // bit for bit it matches forever.  The in-window slots of a chain, numbered consecutively across windows, are
 // cut into segments of kSegSlots slots (>= 3700 samples), and
-//   K3a spec_biquad_kernel   lane per SEGMENT (work queue): runs the segment from a zero state (every segment, the
-//                            chain's first too: the pass needs nothing of the submit before and runs on a stream of
-//                            its own, PipeCtl::ks), stores the truncated outputs the slicers consume, a (yn, yn1)
-//                            checkpoint per slot and the full end state;
+//   K3a spec_biquad_kernel   lane per SEGMENT (work queue): runs the segment from a zero state (the chain's
+//                            first segment from the true carried state), stores the truncated outputs the
+//                            slicers consume, a (yn, yn1) checkpoint per slot and the full end state;
 //   K3b repair_biquad_kernel lane per SEGMENT: runs the head of the segment again, now from the END state of
-//                            the previous segment's speculative run (the chain's first segment: from the true
-//                            carried state), rewriting the outputs until its state
+//                            the previous segment's speculative run, rewriting the outputs until its state
 //                            equals the speculative checkpoint bit for bit -- from there on the stored outputs
 //                            are the continuation of THIS run;
 //   K3c fix_biquad_kernel    lane per CHAIN: walks the segments in order with the true state f.  If f equals the
@@ -704,17 +702,16 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 				f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
 				min_slots = 0;
 				if (MODE == 0) {
-					// EVERY segment from a zero state, the chain's first one too (until round 5 it started from the carried state,
-					// which the chain walk of the submit before writes: the pass of submit k + 1 then had to wait for it and
-					// sat on the TFA_2 family's serial stage loop; now it needs the discriminator pass and the window scan only)
+					if (k == 0)
+						f = L.states[a][s].iir;  // the chain's first segment starts from the true carried state
 				} else if (MODE == 1) {
-					// segment 0 from the TRUE carried state (this pass runs behind the chain walk of the submit before),
-					// segment k > 0 from the speculative end of k - 1
-					f = k > 0 ? biquad_of(T.segend1[sk - 1]) : L.states[a][s].iir;
+					run = k > 0;
+					if (run)
+						f = biquad_of(T.segend1[sk - 1]);
 				} else {
 					// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
 					// the true one, its end state segend2[k-1] is where segment k really starts
-					run = k > 0 && !(T.segfix[sk - 1] & kSegConverged);
+					run = k > 1 && !(T.segfix[sk - 1] & kSegConverged);
 					if (run) {
 						f = biquad_of(T.segend2[sk - 1]);
 						min_slots = T.segfix[sk] & ~kSegConverged;
@@ -843,7 +840,8 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	const double2 *ckrow = T.ckpt + (size_t)(c - T.ck_c0) * T.slots;
 	// the end state of segment kk, IF the last run that wrote it started from the true state
 	auto end_if_good = [&](int kk) -> BiquadEnd {
-		// (segment 0: its repair run K3b started from the carried state, which is the true one)
+		if (kk == 0)
+			return e1[0];  // the speculative run of segment 0 starts from the carried state
 		const size_t sk = (size_t)c * T.segcap + kk;
 		const int fx2 = T.segfix2[sk];
 		const bool second = (fx2 & kSegRan) != 0;
@@ -4135,27 +4133,15 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));
 			mark(25, P.k2);
 		}
-		// The speculative pass needs the discriminator pass and the window scan of ITS submit only (every segment starts from
-		// zero): on a stream of its own (ks) it runs beside the repair passes and the chain walk of the submit before, which
-		// stay on k2 -- k2 carried 5.3 ms of kernels per 5.5 ms period (spec 2.4, repairs 1.3-1.9 + 0.9, walk 0.1-0.6).
-		hipStream_t sp = (P.ks && P.fq && P.fmdev_wmax > 0 && !fm_on_kw) ? P.ks : P.k2;
-		if (sp != P.k2) {
-			TRY(hipStreamWaitEvent(sp, P.ev_win, 0));
-			TRY(hipStreamWaitEvent(sp, P.ev_fm, 0));
-		}
-		mark(1, sp);
+		mark(1, P.k2);
 		if (!(skip & 128))
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize + lds_pad_spec, sp, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize + lds_pad_spec, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		mark(2, sp);
-		if (sp != P.k2) {
-			TRY(hipEventRecord(P.ev_spec, sp));
-			TRY(hipStreamWaitEvent(P.k2, P.ev_spec, 0));
-		}
+		mark(2, P.k2);
 		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
 			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
 			// critical path of the other chains) has had the chip to itself
-			TRY(hipEventRecord(P.ev_fork, sp));
+			TRY(hipEventRecord(P.ev_fork, P.k2));
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}

@@ -311,8 +311,6 @@ struct PipeCtl {
 	// run on cz beside the short windows' slicers on cs (nullptr: one after the other on cs)
 	hipStream_t cz;
 	hipStream_t fq;            // the discriminator pass's own stream (TFREC_AMD_FMDEV_OWN), or nullptr: at the head of k2
-	hipStream_t ks;            // the speculative pass of the TFA_2 family's biquads (TFREC_AMD_SPEC_OWN), or nullptr: at the head of k2
-	hipEvent_t ev_spec;        // ... done (ks): the repair passes on k2 start
 	hipEvent_t ev_heads, ev_coop;
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
 	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
