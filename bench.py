@@ -27,10 +27,13 @@ Rank 0 prints ONE JSON line with the contract fields plus
                   committed rocprofv3 runs of this command (profiles/, named in the block), not from this run.
   "roofline.kernel" is the kernel with the longest live HIP-event span inside the overlapped pipeline (it includes the
                   kernel's waits for issue slots beside the other streams' kernels).
+The steps ROTATE through config.distinct_batches (3) distinct synthetic batches of their own seeds -- A, B, C, A, ... -- so that
+no stream is given the same block twice in a row (engine.cpp:63-93) and every one of the library's four buffer sets holds
+every batch in turn.
 Parity gates: BEFORE the timed region, on fresh state, EVERY stream of the batch at N=1 (128 spread over the batch per
 rank at N>1) against the CPU oracle; AFTER it one more batch through the same context (carried decoder / biquad / slicer
-state, FIFO four deep) with 64 streams against the oracle continued over every repetition of the input the context has
-seen (config.parity_after_timed*); and the discriminator's self-check counters (config.atan_*: samples decided by the
+state, FIFO four deep) with 64-256 streams against the oracle run over the TRUE concatenation of all batches the context has
+seen, in their order (config.parity_after_timed*); and the discriminator's self-check counters (config.atan_*: samples decided by the
 exact slow path / differing from this host's libm).  A mismatch in any of them fails the run.
 """
 from __future__ import annotations
@@ -215,6 +218,13 @@ def main():
     ap.add_argument("--bg-traffic-gb", type=float, default=0.0,
                     help="EXPERIMENT (what binds?): beside every batch, a device-to-device copy of this many GB of HBM traffic (half read, "
                          "half written, coalesced) on a stream of its own; the line then carries config.bg_traffic_gb and is not a result")
+    ap.add_argument("--distinct-batches", type=int, default=3,
+                    help="distinct synthetic batches (own seeds) the steps rotate through: A, B, C, A, ...  A stream never sees "
+                         "the same block twice in a row (engine.cpp:63-93), and with 3 batches over the library's 4 buffer sets "
+                         "every set holds every batch in turn: a stale buffer cannot pass the gate behind the timed region")
+    ap.add_argument("--experiments", action="store_true",
+                    help="A/B sessions only: load libtfrec_amd_exp.so (environment knobs compiled in, csrc/knobs.h) instead of the "
+                         "product library; the line then carries config.library = 'experiments' and is not a result")
     ap.add_argument("--input-10x", action="store_true",
                     help="BASELINE config 5 instead of config 2: 15.36 MS/s input through the 10:1 front end "
                          "(secondary measurement; the default line stays config 2)")
@@ -264,32 +274,47 @@ def main():
     ncpu = os.cpu_count() or 1
     unique = a.unique if a.unique > 0 else (n_streams if ncpu >= 32 else min(n_streams, max(16, 8 * ncpu)))
     t0 = time.perf_counter()
-    if rate == 1:
-        host = synth.gen_batch(1000 + rank, rank * n_streams, unique, n_blocks)
-    else:
+    n_distinct = max(1, a.distinct_batches)
+    if rate != 1:
         unique = min(unique, 32)
-        host = np.stack([synth.gen_stream(1000 + rank, rank * n_streams + s, n_blocks, 0x1F, 256, rate_mult=rate)
-                         for s in range(unique)])
+    # batch b of the rotation: its own seed (1000 + rank + 7919 b); batch q of the run is hosts[q % n_distinct]
+    hosts = []
+    for b in range(n_distinct):
+        if rate == 1:
+            hosts.append(synth.gen_batch(1000 + rank + 7919 * b, rank * n_streams, unique, n_blocks))
+        else:
+            hosts.append(np.stack([synth.gen_stream(1000 + rank + 7919 * b, rank * n_streams + s, n_blocks, 0x1F, 256, rate_mult=rate)
+                                   for s in range(unique)]))
+    host = hosts[0]
     t_gen = time.perf_counter() - t0
     import zlib
     input_crc = shard.gather_ints(zlib.crc32(host[0].tobytes()), red_dev)  # every rank generates its own streams
-    d_iq = torch.empty((n_streams, row), dtype=torch.uint8, device=dev)
-    d_u = torch.from_numpy(host).to(dev)
-    for s0 in range(0, n_streams, unique):
-        k = min(unique, n_streams - s0)
-        d_iq[s0:s0 + k].copy_(d_u[:k])
-    del d_u
+    d_batches = []
+    for hb in hosts:
+        d_b = torch.empty((n_streams, row), dtype=torch.uint8, device=dev)
+        d_u = torch.from_numpy(hb).to(dev)
+        for s0 in range(0, n_streams, unique):
+            k = min(unique, n_streams - s0)
+            d_b[s0:s0 + k].copy_(d_u[:k])
+        del d_u
+        d_batches.append(d_b)
     torch.cuda.synchronize(dev)
+    seq = [0]  # batches this context has been given so far: the next one is number seq[0] of the rotation
+
+    def next_batch():
+        b = d_batches[seq[0] % n_distinct]
+        seq[0] += 1
+        return b
 
     r = api.Receiver(n_streams, a.types, a.thresh, 0, device=dev_index, max_blocks=n_blocks, timing=True,
-                     max_events=max(4096, n_streams * 256), input_10x=a.input_10x)
+                     max_events=max(4096, n_streams * 256), input_10x=a.input_10x, experiments=a.experiments)
 
     # ---- parity gate (fresh context state): GPU events of the first batch == oracle events, stream by stream
     parity_ok = None
     parity_n = 0
     if a.parity_streams != 0:
         from oracle import oracle as O
-        r.submit(d_iq)
+        r.submit(next_batch())  # batch 0 of the rotation = hosts[0]
         first = r.drain()
         want_n = a.parity_streams if a.parity_streams > 0 else (n_streams if world == 1 else 128)
         want_n = min(want_n, n_streams)
@@ -340,7 +365,7 @@ def main():
         queued = 0
         for k in range(n_steps):
             while queued < n_steps and queued - k < depth:
-                r.submit(d_iq if src is None else src)
+                r.submit(next_batch() if src is None else src)
                 queued += 1
                 if bg is not None:
                     with torch.cuda.stream(bg[2]):
@@ -376,8 +401,9 @@ def main():
     parity_after_n = 0
     if a.parity_streams != 0 and rate == 1:
         from oracle import oracle as O
-        reps_before = (1 if parity_ok is not None else 0) + a.warmup + a.steps
-        r.submit(d_iq)
+        reps_before = seq[0]  # gate + warm-up + timed steps
+        assert reps_before == (1 if parity_ok is not None else 0) + a.warmup + a.steps
+        r.submit(next_batch())
         last = r.drain()
         # (the oracle has to run every checked stream over ALL repetitions: 256 streams on the driver's short line, fewer on long ones)
         after_n = a.parity_after_streams if a.parity_after_streams > 0 else max(64, min(256, 256 * 32 // max(1, reps_before)))
@@ -385,8 +411,10 @@ def main():
         pick = np.unique(np.linspace(0, n_streams - 1, want_n).round().astype(np.int64))
         src = np.unique(pick % unique)
         t_or = time.perf_counter()
-        orc = dict(zip(src.tolist(), O.process_parts([host[src], host[src]], a.types, a.thresh, 0, reps=[reps_before, 1],
-                                                     keep_from=1)))
+        # the TRUE concatenation: batch q of the rotation is hosts[q % n_distinct], every one of the reps_before + 1 in order
+        parts_ = [hb[src] for hb in hosts]
+        orc = dict(zip(src.tolist(), O.process_parts([parts_[q % n_distinct] for q in range(reps_before + 1)], a.types, a.thresh, 0,
+                                                     keep_from=reps_before)))
         t_or = time.perf_counter() - t_or
         minb = np.array([10, 7, 7, 7, 11])
         gs, gm = api.events_canon(last)
@@ -420,7 +448,7 @@ def main():
     if a.h2d_steps > 0 and world == 1:
         try:
             import ctypes as C
-            L = api.load_library()
+            L = r.L
             L.tfrec_amd_host_alloc.restype = C.c_void_p
             L.tfrec_amd_host_alloc.argtypes = [C.c_size_t]
             L.tfrec_amd_host_free.argtypes = [C.c_void_p]
@@ -466,9 +494,18 @@ def main():
             xdu = torch.from_numpy(xh).to(dev)
             for s0 in range(0, xs, xu):
                 xd[s0:s0 + min(xu, xs - s0)].copy_(xdu[:min(xu, xs - s0)])
+            # the leg's second batch: the same recordings given to the NEXT stream each (stream s gets stream s - 1's), so that no
+            # stream sees the same block twice in a row; the steps alternate between the two
+            xrot = (xd, torch.roll(xd, 1, 0))
+            xq = [0]
+
+            def xnext():
+                xq[0] += 1
+                return xrot[(xq[0] - 1) & 1]
+
             with api.Receiver(xs, xt, xth, 0, device=dev_index, max_blocks=xb, max_events=max(4096, xs * 256),
-                              input_10x=x10, timing=bool(want_kernels)) as xr_:
-                xr_.submit(xd)
+                              input_10x=x10, timing=bool(want_kernels), experiments=a.experiments) as xr_:
+                xr_.submit(xnext())
                 first = xr_.drain()
                 ok = True
                 minb = {0: 10, 1: 7, 2: 7, 3: 7, 4: 11}
@@ -487,14 +524,14 @@ def main():
                         ok = ok and xr_.thresh(k) == o.thresh()
                 q = 0
                 for k in range(3):  # warm-up
-                    xr_.submit(xd)
+                    xr_.submit(xnext())
                     xr_.drain()
                 torch.cuda.synchronize(dev)
                 tx = time.perf_counter()
                 kk = {}
                 for k in range(steps):
                     while q < steps and q - k < depth:
-                        xr_.submit(xd)
+                        xr_.submit(xnext())
                         q += 1
                     xr_.drain()
                     if want_kernels:
@@ -504,7 +541,8 @@ def main():
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - tx
             xalg = algorithmic_floor_ms(xs, xb, xt) if not x10 else None
-            extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, thresh=xth, input_10x=x10, steps=steps, parity_ok=ok,
+            del xrot
+            extra[name] = dict(streams=xs, blocks=xb, types_mask=xt, thresh=xth, input_10x=x10, steps=steps, parity_ok=ok, distinct_batches=2,
                                parity_streams_checked=xu, parity_events_checked=n_want,
                                ms_per_step=round(dt / steps * 1e3, 4),
                                hbm_frac=round(2.0 * xs * xb * SAMPLES_PER_BLOCK * xr / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
@@ -673,6 +711,10 @@ def main():
                             % (n_streams, n_blocks, a.types, a.thresh),
                 "streams_per_gpu": n_streams, "blocks_per_stream": n_blocks, "types_mask": a.types,
                 "thresh": a.thresh, "parallelism": "streams sharded by index, no collective",
+                # the steps rotate through this many distinct batches (own seeds); the gate behind the timed region runs the
+                # oracle over their true concatenation
+                "distinct_batches": n_distinct,
+                "library": "experiments (csrc/knobs.h: NOT a result)" if a.experiments else "product (no environment knobs)",
                 "events_per_step": n_events // max(1, a.steps), "parity_gate_streams": parity_n,
                 "parity_ok": parity_ok, "gen_seconds": round(t_gen, 2),
                 # the batch after the timed region (state carried over gate + warm-up + timed steps, FIFO `depth` deep)

@@ -2,7 +2,9 @@
 """A/B on ONE GPU box: bench.py for each (label, library build, environment) of a spec, alternating, `rounds` times.
 
 usage: profiles/ab_run.py <out.jsonl> <rounds> <steps> <warmup> label=LIB[,VAR=val,...] ...
-  LIB = "default" (tfrec_amd/libtfrec_amd.so) or the name of a build under tfrec_amd/ab/ (profiles/build_variant.sh).
+  LIB = "default" (round 6 on: tfrec_amd/libtfrec_amd_exp.so, the build that reads the TFREC_AMD_* knobs -- the product library
+  has none, csrc/knobs.h; "product" = tfrec_amd/libtfrec_amd.so, no VAR allowed) or the name of a build under tfrec_amd/ab/
+  (profiles/build_variant.sh, which compiles with -DTFREC_AMD_EXPERIMENTS).
 One line per run on stdout (ms_per_step, steady, min/median, parity, the longest kernels), the full bench lines in out.jsonl.
 """
 import json
@@ -16,15 +18,17 @@ specs = []
 for a in sys.argv[5:]:
     label, rest = a.split("=", 1)
     parts = rest.split(",")
-    lib = os.path.join(R, "tfrec_amd", "libtfrec_amd.so") if parts[0] == "default" else os.path.join(R, "tfrec_amd", "ab", parts[0] + ".so")
+    lib = (None if parts[0] == "product" else os.path.join(R, "tfrec_amd", "libtfrec_amd_exp.so") if parts[0] == "default"
+           else os.path.join(R, "tfrec_amd", "ab", parts[0] + ".so"))
     env = dict(p.split("=", 1) for p in parts[1:])
     specs.append((label, lib, env))
 extra = os.environ.get("AB_BENCH_ARGS", "--cpu-budget 0 --h2d-steps 0 --parity-streams 8 --no-extra-configs").split()
 with open(out_path, "a") as fo:
     for r in range(rounds):
         for label, lib, env in specs:
-            e = dict(os.environ, TFREC_AMD_LIB=lib, **env)
-            p = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--steps", str(steps), "--warmup", str(warmup)] + extra,
+            e = dict(os.environ, **env) if lib is None else dict(os.environ, TFREC_AMD_LIB=lib, **env)
+            p = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--steps", str(steps), "--warmup", str(warmup)] + extra
+                               + ([] if lib is None else ["--experiments"]),
                                env=e, capture_output=True, text=True)
             try:
                 j = json.loads(p.stdout.strip().splitlines()[-1])

@@ -32,8 +32,11 @@ def _round(rng, rnd, verbose):
                        for s in range(n_streams)])
         cuts = sorted(set([0, n_blocks] + [int(x) for x in rng.integers(1, n_blocks, size=int(rng.integers(0, 4)))]))
         mb = max(b - a for a, b in zip(cuts, cuts[1:]))
-        os.environ["TFREC_AMD_DEEP"] = str(int(rng.integers(0, 2)))  # pipeline layout: read when the context is created
-        with api.Receiver(n_streams, types, thresh, wide, max_blocks=mb, all_flushes=True, max_events=400000) as r:
+        # two rounds in three: the product library; the third: the experiments build (csrc/knobs.h) with a random pipeline layout
+        exp = int(rng.integers(0, 3)) == 0
+        if exp:
+            os.environ["TFREC_AMD_DEEP"] = str(int(rng.integers(0, 2)))  # read when the context is created
+        with api.Receiver(n_streams, types, thresh, wide, max_blocks=mb, all_flushes=True, max_events=400000, experiments=exp) as r:
             evs = []
             k = 0
             pend = 0

@@ -28,6 +28,54 @@ def test_library_exports_every_declared_symbol():
     assert C.sizeof(api.Config) == 32 and api.EVENT_DTYPE.itemsize == 96
 
 
+def test_product_library_has_no_environment_knobs_and_the_experiments_build_exports_the_same_abi():
+    """csrc/knobs.h: the library bench.py and the adapter load is built without TFREC_AMD_EXPERIMENTS -- no getenv import, no knob
+    name, no what-if switch or test hook in the binary; libtfrec_amd_exp.so (same sources) has them and the same C ABI."""
+    import subprocess
+    from tfrec_amd import _build
+
+    api.load_library()
+    Lx = api.load_library(experiments=True)
+    for name in api.EXPORTS:
+        assert getattr(Lx, name) is not None
+    prod = open(_build.LIB_SO, "rb").read()
+    expl = open(_build.LIB_EXP_SO, "rb").read()
+    for knob in (b"TFREC_AMD_SKIP", b"TFREC_AMD_WHB_FORCE_FAIL", b"TFREC_AMD_WHB_TEST_PERTURB", b"TFREC_AMD_LANES_", b"_DIV",
+                 b"TFREC_AMD_LDS_PAD", b"TFREC_AMD_DEEP", b"TFREC_AMD_"):
+        assert knob not in prod, knob
+    assert b"TFREC_AMD_SKIP" in expl and b"TFREC_AMD_WHB_FORCE_FAIL" in expl
+    # ... and it does not import getenv at all
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _build.LIB_SO], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", _build.LIB_EXP_SO], capture_output=True, text=True,
+                                      check=True).stdout
+
+
+def test_build_staleness_is_decided_by_content(tmp_path):
+    """tfrec_amd/_build.py: an object is current iff its stamp equals the SHA-256 of its sources, headers and flags -- time
+    stamps play no part (a snapshot copy refreshes them), and an edited header makes every object stale."""
+    from tfrec_amd import _build
+
+    src = tmp_path / "a.hip"
+    hdr = tmp_path / "a.h"
+    obj = tmp_path / "a.o"
+    src.write_text("int f();")
+    hdr.write_text("// 1")
+    obj.write_text("object")
+    d1 = _build._digest([str(src), str(hdr)], "-O3")
+    assert not _build._current(str(obj), d1)  # no stamp yet
+    _build._stamp(str(obj), d1)
+    assert _build._current(str(obj), d1)
+    os.utime(str(src), (10**9 * 2, 10**9 * 2))  # a newer time stamp alone changes nothing
+    assert _build._current(str(obj), _build._digest([str(src), str(hdr)], "-O3"))
+    hdr.write_text("// 2")
+    assert not _build._current(str(obj), _build._digest([str(src), str(hdr)], "-O3"))
+    assert not _build._current(str(obj), _build._digest([str(src), str(hdr)], "-O2"))  # ... nor do other flags
+    _build.build_all()
+    acts = _build.last_actions()
+    assert any("libtfrec_amd.so" in a for a in acts) and any("libtfrec_amd_exp.so" in a for a in acts)
+
+
 def test_argument_validation_precedes_device_use():
     L = api.load_library()
     h = C.c_void_p()

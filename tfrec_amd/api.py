@@ -92,24 +92,27 @@ EXPORTS = (
     "tfrec_amd_fifo_depth", "tfrec_amd_get_memory",
 )
 
-_lib = None
+_libs = {}
 
 
-def library_path() -> str:
-    return _build.LIB_SO
+def library_path(experiments: bool = False) -> str:
+    return _build.LIB_EXP_SO if experiments else _build.LIB_SO
 
 
-def load_library(build: bool = True):
-    """Load libtfrec_amd.so (building it in-tree first when hipcc is available).  Raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(build: bool = True, experiments: bool = False):
+    """Load libtfrec_amd.so -- or, experiments=True, libtfrec_amd_exp.so: the same sources with the environment knobs and
+    test hooks compiled in (csrc/knobs.h) -- building it in-tree first when hipcc is available.  Raises if absent."""
+    key = bool(experiments)
+    if key in _libs:
+        return _libs[key]
     if build:
         try:
-            _build.build_device_lib()
+            _build.build_device_lib(experiments=key)
         except (OSError, FileNotFoundError):
             pass  # no hipcc on this box: use the prebuilt library that travelled with the tree
-    lib_so = os.environ.get("TFREC_AMD_LIB", _build.LIB_SO)  # (A/B experiments: an alternative build of the library)
+    lib_so = library_path(key)
+    if key:
+        lib_so = os.environ.get("TFREC_AMD_LIB", lib_so)  # (A/B sessions: an alternative experiments build)
     if not os.path.exists(lib_so):
         raise RuntimeError("HIP extension %s is missing: run __graft_entry__.build()" % lib_so)
     # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing torch first makes our
@@ -147,7 +150,7 @@ def load_library(build: bool = True):
     if L.tfrec_amd_fifo_depth() != FIFO_DEPTH:
         raise RuntimeError("libtfrec_amd.so was built with FIFO depth %d, this binding expects %d" % (
             L.tfrec_amd_fifo_depth(), FIFO_DEPTH))
-    _lib = L
+    _libs[key] = L
     return L
 
 
@@ -171,8 +174,11 @@ class Receiver:
 
     def __init__(self, n_streams: int, types_mask: int = 0x2F, thresh: int = 500, filter_type: int = 0,
                  device: int = 0, max_blocks: int = 48, max_events: int | None = None, all_flushes: bool = False,
-                 timing: bool = False, serial_chains: bool = False, input_10x: bool = False, bits: bool = False):
-        self.L = load_library()
+                 timing: bool = False, serial_chains: bool = False, input_10x: bool = False, bits: bool = False,
+                 experiments: bool = False):
+        # experiments=True: the build that reads the TFREC_AMD_* knobs / test hooks from the environment (csrc/knobs.h);
+        # the default is the product library, which has none
+        self.L = load_library(experiments=experiments)
         if max_events is None:
             max_events = max(4096, n_streams * max_blocks * 4 * (8 if all_flushes else 2))
         flags = ((F_ALL_FLUSHES if all_flushes else 0) | (F_TIMING if timing else 0)

@@ -8,6 +8,7 @@
 #include <new>
 #include <vector>
 
+#include "knobs.h"
 #include "tfrec_dev.h"
 
 namespace tfrec {
@@ -272,11 +273,11 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 {
 	if (!c)
 		return TFREC_AMD_OK;
-	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_n)
+	if (TFREC_KNOB_STR("HOST_PROF") && c->hp_n)
 		fprintf(stderr, "tfrec_amd host time per batch: submit %.0f us, drain: wait %.0f + copy %.0f + sort %.0f us (%ld batches)\n",
 			1e6 * c->hp_submit / c->hp_n, 1e6 * c->hp_wait / c->hp_n, 1e6 * c->hp_copy / c->hp_n, 1e6 * c->hp_sort / c->hp_n,
 			c->hp_n);
-	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_gap_n)
+	if (TFREC_KNOB_STR("HOST_PROF") && c->hp_gap_n)
 		fprintf(stderr, "tfrec_amd front-end stream: %.3f ms between one submit's front end and the next one's; front-end start -> TFA_1 chain end %.2f ms; front-end start to start %.3f ms (%ld batches)\n",
 			c->hp_gap / c->hp_gap_n, c->hp_lat / c->hp_gap_n, c->hp_s2s / c->hp_gap_n, c->hp_gap_n);
 	(void)hipSetDevice(c->cfg.device);
@@ -391,9 +392,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	if (!c)
 		return TFREC_AMD_E_NOMEM;
 	c->cfg = *cfg;
-	if (const char *fe = getenv("TFREC_AMD_FM_FLAG_EPS"))
+	if (const char *fe = TFREC_KNOB_STR("FM_FLAG_EPS"))
 		c->fm_flag_eps = std::max(1e-9, atof(fe));
-	if (const char *cg = getenv("TFREC_AMD_COPY_GUESS_MIN"))
+	if (const char *cg = TFREC_KNOB_STR("COPY_GUESS_MIN"))
 		c->copy_guess = c->copy_guess_min = (uint32_t)std::max(1, atoi(cg));
 	memset(&c->launch, 0, sizeof(c->launch));
 	memset(&c->win, 0, sizeof(c->win));
@@ -515,15 +516,17 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			ALLOC(c->d_whbscr, n * sizeof(ChainState));
 			// TEST hooks (results stay exact under both: the check's tolerance and the ambiguity rule widen with D, and a forced
 			// failure is only a redo) -- clamped, and never silent: a stray variable changes the redo rate, i.e. the speed
-			if (const char *tp = getenv("TFREC_AMD_WHB_TEST_PERTURB"))
+			if (const char *tp = TFREC_KNOB_STR("WHB_TEST_PERTURB"))
 				c->whb_test_perturb = std::max(-1000000, std::min(1000000, atoi(tp)));
 			if (rc == TFREC_AMD_OK && hipMemset(c->d_whbgen, 0, n * sizeof(uint32_t)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
-			if (const char *ff = getenv("TFREC_AMD_WHB_FORCE_FAIL"))
+			if (const char *ff = TFREC_KNOB_STR("WHB_FORCE_FAIL"))
 				c->whb_force_fail = std::max(0, atoi(ff));
+#if TFREC_KNOBS_BUILT
 			if (c->whb_test_perturb || c->whb_force_fail)
 				fprintf(stderr, "tfrec_amd: TEST hook active (TFREC_AMD_WHB_TEST_PERTURB=%d, TFREC_AMD_WHB_FORCE_FAIL=%d): WHB streams are "
 						"redone on purpose, results unchanged, throughput lower\n", c->whb_test_perturb, c->whb_force_fail);
+#endif
 			if (rc == TFREC_AMD_OK && (hipMemset(c->d_whbx, 0, n * sizeof(WhbExact)) != hipSuccess ||
 						   hipMemset(c->d_whbcarry, 0, n * sizeof(int)) != hipSuccess))
 				rc = TFREC_AMD_E_HIP;
@@ -615,8 +618,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.whbscr = c->d_whbscr;
 			T.whbpub = nullptr;
 			T.whb_test_perturb = c->whb_test_perturb;
-			T.tfa1_vec = !(getenv("TFREC_AMD_TFA1_VEC") && atoi(getenv("TFREC_AMD_TFA1_VEC")) == 0);
-			T.tfa2_vec = !(getenv("TFREC_AMD_TFA2_VEC") && atoi(getenv("TFREC_AMD_TFA2_VEC")) == 0);
+			T.tfa1_vec = TFREC_KNOB_INT("TFA1_VEC", 1, 0, 1) != 0;
+			T.tfa2_vec = TFREC_KNOB_INT("TFA2_VEC", 1, 0, 1) != 0;
 			T.whb_force_fail = c->whb_force_fail;
 			T.whbx = c->d_whbx;
 			T.timeout_carry = c->d_tcarry;
@@ -666,9 +669,9 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 	// with three submits in flight, became the longest stage of all: 13.4 ms per batch instead of 11.7.
 	int prio_lo = 0, prio_hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-	const int prio_fs = getenv("TFREC_AMD_PRIO_FS") ? atoi(getenv("TFREC_AMD_PRIO_FS")) : prio_hi;
+	const int prio_fs = TFREC_KNOB_STR("PRIO_FS") ? atoi(TFREC_KNOB_STR("PRIO_FS")) : prio_hi;
 	// (experiments: TFREC_AMD_PRIO = one letter h / n / l per stream in the order fs cp cs t1 aux k2 kw, default "hnhhhnn")
-	const char *prio_env = getenv("TFREC_AMD_PRIO");
+	const char *prio_env = TFREC_KNOB_STR("PRIO");
 	auto prio_of = [&](int k, int dflt) {
 		if (!prio_env || strlen(prio_env) <= (size_t)k)
 			return dflt;
@@ -710,7 +713,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		if (mkstream(&c->t1, 3, prio_hi) != hipSuccess || mkstream(&c->aux, 4, prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 		// deep layout (default; TFREC_AMD_DEEP=0 selects the shallow one): the biquad stages get streams of their own
-		const char *dp = getenv("TFREC_AMD_DEEP");
+		const char *dp = TFREC_KNOB_STR("DEEP");
 		c->deep = dp ? atoi(dp) != 0 : true;
 		// The discriminator pass moves from the front-end stream to the head of the TFA_2-family biquad stage when a WHB
 		// demodulator is registered: then the WHB chain is the longest and the front-end stream the busiest (measured
@@ -718,8 +721,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		bool has_whb = false;
 		for (int a = 0; a < c->launch.n_active; a++)
 			has_whb = has_whb || c->launch.params[a].kind == 2;
-		c->scan_on_kw = getenv("TFREC_AMD_SCAN_KW") ? atoi(getenv("TFREC_AMD_SCAN_KW")) != 0 : true;
-		c->fmdev_k2 = getenv("TFREC_AMD_FMDEV_K2") ? atoi(getenv("TFREC_AMD_FMDEV_K2")) != 0 : has_whb;
+		c->scan_on_kw = TFREC_KNOB_INT("SCAN_KW", 1, 0, 1) != 0;
+		c->fmdev_k2 = TFREC_KNOB_INT("FMDEV_K2", has_whb ? 1 : 0, 0, 1) != 0;
 		c->k2 = c->cs;
 		c->kw = c->aux;
 		c->vx = c->aux;
@@ -728,8 +731,8 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			rc = TFREC_AMD_E_HIP;
 		// TFREC_AMD_COOP_STREAM=1: a stream for the TFA_2 family's cooperative slicers (PipeCtl::cz).  It is the fifth of high
 		// priority: with the HIP default of four hardware queues per priority it shares one (GPU_MAX_HW_QUEUES >= 8 wanted).
-		if (c->deep && rc == TFREC_AMD_OK && getenv("TFREC_AMD_COOP_STREAM") && atoi(getenv("TFREC_AMD_COOP_STREAM")) != 0 &&
-		    hipStreamCreateWithPriority(&c->cz, hipStreamNonBlocking, atoi(getenv("TFREC_AMD_COOP_STREAM")) == 2 ? 0 : prio_hi) != hipSuccess)
+		if (c->deep && rc == TFREC_AMD_OK && TFREC_KNOB_INT("COOP_STREAM", 0, 0, 2) != 0 &&
+		    hipStreamCreateWithPriority(&c->cz, hipStreamNonBlocking, TFREC_KNOB_INT("COOP_STREAM", 0, 0, 2) == 2 ? 0 : prio_hi) != hipSuccess)
 			rc = TFREC_AMD_E_HIP;
 		// The discriminator pass on a LOW-priority stream of its own (TFREC_AMD_FMDEV_OWN: 0 = at the head of k2, 1 = low
 		// (default when a WHB demodulator is registered), 2 = normal, 3 = high priority).  It needs the front end only, not
@@ -737,7 +740,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		// batch period: 6.98 -> 6.60 ms per batch over 100 steps (profiles/r04_ab_fmdev_stream.txt).  The low-priority pool's
 		// hardware queues are otherwise unused, so the stream shares none (a fifth normal-priority stream would).
 		{
-			const int m = getenv("TFREC_AMD_FMDEV_OWN") ? atoi(getenv("TFREC_AMD_FMDEV_OWN")) : (c->fmdev_k2 ? 1 : 0);
+			const int m = TFREC_KNOB_INT("FMDEV_OWN", c->fmdev_k2 ? 1 : 0, 0, 3);
 			if (c->deep && rc == TFREC_AMD_OK && m > 0 && c->need_fmdev && c->fmdev_k2 &&
 			    hipStreamCreateWithPriority(&c->fq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
@@ -747,7 +750,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		// before the TFA chains of submit k had ended.  6.32 -> 6.21 ms per batch over 100 steps
 		// (profiles/r04_ab_copy_stream.txt); the low pool's hardware queues hold only this stream and the discriminator's.
 		{  // (TFREC_AMD_COPY_OWN: 0 = on cp, 1 = low priority (default), 2 = normal, 3 = high)
-			const int m = getenv("TFREC_AMD_COPY_OWN") ? atoi(getenv("TFREC_AMD_COPY_OWN")) : 1;
+			const int m = TFREC_KNOB_INT("COPY_OWN", 1, 0, 3);
 			if (c->deep && rc == TFREC_AMD_OK && m > 0 &&
 			    hipStreamCreateWithPriority(&c->cq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
@@ -826,7 +829,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	}
 	// (TFREC_AMD_SKIP bit 512, WHAT-IF timing only: after the first 12 submits the front end is left out and the chains run
 	// on what the buffer set holds from four submits ago -- what the front end costs the batch period)
-	static const bool whatif_no_fe = getenv("TFREC_AMD_SKIP") && (atoi(getenv("TFREC_AMD_SKIP")) & 512);
+	static const bool whatif_no_fe = (TFREC_KNOB_INT("SKIP", 0, 0, 1 << 16) & 512) != 0;
 	static int whatif_submits = 0;
 	if (!(whatif_no_fe && ++whatif_submits > 12))
 	HIPCHK(launch_frontend(fs, fin, fstride, c->cfg.n_streams, n_blocks, c->d_tail[c->tail_sel],
@@ -903,7 +906,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		fprintf(stderr, "COOPSTAT (one submit) TFA_2 family: frozen one-block steps %llu, accepted %llu, rejected %llu, other frozen steps %llu; TFA_1: steps %llu, candidate runs %llu; TFA_2 walked steps with a full mask %llu, candidates in walked steps %llu, walked steps that begin inside a run %llu\n", st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
 	}
 #endif
-	if (getenv("TFREC_AMD_DEBUG_WINHIST") && c->submit_seq == 3) {  // (debug: the window length distribution of one submit)
+	if (TFREC_KNOB_STR("DEBUG_WINHIST") && c->submit_seq == 3) {  // (debug: the window length distribution of one submit)
 		(void)hipDeviceSynchronize();
 		const WinTables &T = c->win[set];
 		const size_t chains = (size_t)c->launch.n_active * c->cfg.n_streams;
@@ -935,7 +938,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 			fprintf(stderr, "\n");
 		}
 	}
-	if (getenv("TFREC_AMD_DEBUG_CONVHIST") && c->submit_seq == 3 && !(c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)) {
+	if (TFREC_KNOB_STR("DEBUG_CONVHIST") && c->submit_seq == 3 && !(c->cfg.flags & TFREC_AMD_F_SERIAL_CHAINS)) {
 		// (debug: after how many 32-sample slots the first repair run of a biquad segment -- started from the end state of the
 		// segment before -- became bit-identical to the segment's own run from a zero state: the convergence-time distribution
 		// of the speculation, per chain; a build with -DTFREC_AMD_CK_EVERY=1 resolves it to one slot)
@@ -1305,7 +1308,7 @@ int tfrec_amd_get_timings(tfrec_amd_ctx *c, tfrec_amd_timings *out)
 	for (auto &e : c->done[set])
 		HIPCHK(hipEventSynchronize(e));
 	HIPCHK(hipEventElapsedTime(&out->frontend_ms, ev[0], ev[3]));
-	if (getenv("TFREC_AMD_HOST_PROF") && c->hp_n > 2) {  // idle time of the front-end stream between two submits' front ends
+	if (TFREC_KNOB_STR("HOST_PROF") && c->hp_n > 2) {  // idle time of the front-end stream between two submits' front ends
 		float gap = 0, total = 0;
 		const int next = (set + 1) % kSets;  // (in flight: its front end started long ago)
 		if (hipEventElapsedTime(&gap, ev[3], c->ev[next][0]) == hipSuccess && hipEventElapsedTime(&total, ev[0], tev[20]) == hipSuccess &&

@@ -39,19 +39,32 @@
 #include <algorithm>
 
 #include "decoder_dev.h"
+#include "knobs.h"
 #include "whb_chain_asm.h"
 
 namespace tfrec {
 
-// experiment knobs: integer from the environment, `dflt` when unset or outside [lo, hi]
-static int env_int(const char *name, int dflt, int lo = 0, int hi = 1 << 30)
-{
-	const char *v = getenv(name);
-	const int x = v ? atoi(v) : dflt;
-	return x >= lo && x <= hi ? x : dflt;
-}
+// experiment knobs (knobs.h): read from the environment only in the -DTFREC_AMD_EXPERIMENTS build
 
 constexpr int kSpecLbi = -(1 << 30);  // "last edge far in the past"
+
+// The WHB test hooks (knobs.h: forced failures of the check, a perturbed frozen average) exist in the experiments build only
+__device__ __forceinline__ int whb_hook_perturb(const WinTables &T)
+{
+#ifdef TFREC_AMD_EXPERIMENTS
+	return T.whb_test_perturb;
+#else
+	return 0;
+#endif
+}
+__device__ __forceinline__ int whb_hook_force_fail(const WinTables &T)
+{
+#ifdef TFREC_AMD_EXPERIMENTS
+	return T.whb_force_fail;
+#else
+	return 0;
+#endif
+}
 
 // tfa1.cpp:159 "mark_lvl = (int)(mark_lvl * 0.95)" for mark_lvl >= 0 (the peak detector never goes negative) without the
 // trip through a double: the double nearest 0.95 is 0.95 - 4.4e-17, so the exact product is m * 19 / 20 minus less than
@@ -2909,7 +2922,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		// A candidate test against the frozen average is AMBIGUOUS if it would come out differently with the average up to
 		// `tol` higher or lower: avg_of - dev in [-tol + 1, tol].  tol = 1 (the speculated (int) may be the exact one's
 		// neighbour); tests widen it and perturb the frozen integer (WinTables::whb_test_perturb).
-		const int perturb = EXACT ? 0 : T.whb_test_perturb;
+		const int perturb = EXACT ? 0 : whb_hook_perturb(T);
 		const int amb_tol = perturb > 1 ? perturb : (perturb < -1 ? -perturb : 1);
 		const int amb_lo = amb_tol - 1;
 		const uint32_t amb_w = 2u * (uint32_t)amb_tol;
@@ -3439,7 +3452,8 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 	int fd1 = st.fd1, fd2 = st.fd2;
 	int carry = carry_io[sc_];  // exact minus speculated frozen average of a window still open and locked (0, +1, -1)
 	const int carry_in = carry;
-	const int tol = T.whb_test_perturb > 1 ? T.whb_test_perturb : (T.whb_test_perturb < -1 ? -T.whb_test_perturb : 1);
+	const int tp_ = whb_hook_perturb(T);
+	const int tol = tp_ > 1 ? tp_ : (tp_ < -1 ? -tp_ : 1);
 	bool bad = false, done = !active;
 	// ---- the rings: R[k] = record of step v + k, D[k][q] = the lane's samples 16 q + li of step v + k
 	uint4 R[kVerRecAhead + 1];
@@ -3565,7 +3579,7 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 		T.whbx0[s] = st;  // the exact state this submit started from, and the carry (a redo needs both)
 		// a stream whose speculative pass started from a state that a redo has replaced since is redone as well
 		bad = bad || T.whbseen[s] != T.whbgen[s];
-		if (T.whb_force_fail > 0 && (s + T.whb_submit_seq) % T.whb_force_fail == 0)
+		if (whb_hook_force_fail(T) > 0 && (s + T.whb_submit_seq) % whb_hook_force_fail(T) == 0)
 			bad = true;  // tests
 		st.y1 = y1;
 		st.y2 = y2;
@@ -3915,7 +3929,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			(void)hipEventRecord(P.tev[k], s_);
 	};
 	// WHAT-IF experiments only (results are wrong): leave kernels out to see what each costs the batch period
-	static const int skip = env_int("TFREC_AMD_SKIP", 0, 0, 1 << 16);
+	static const int skip = TFREC_KNOB_INT("SKIP", 0, 0, 1 << 16);
 	hipError_t e = hipSuccess;
 #define TRY(x)                          \
 	do {                            \
@@ -3929,7 +3943,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	}
 	// Lanes per wave for the serial kernels (tunable for experiments: TFREC_AMD_LANES_*).  Measured on MI355X:
 	// fewer lanes per wave (less lock-step divergence, more waves) is NOT faster -- full waves win.
-	static const int lanes_chain = env_int("TFREC_AMD_LANES_CHAIN", 64, 1, 64), lanes_win = env_int("TFREC_AMD_LANES_WIN", 64, 1, 64);
+	static const int lanes_chain = TFREC_KNOB_INT("LANES_CHAIN", 64, 1, 64), lanes_win = TFREC_KNOB_INT("LANES_WIN", 64, 1, 64);
 	dim3 block(64);
 	dim3 grid((n_streams + lanes_chain - 1) / lanes_chain, L.n_active);
 	const int win_blocks = std::min(16384, (int)(((size_t)n_streams * n_blocks * 2 + lanes_win - 1) / lanes_win));
@@ -3940,22 +3954,22 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	// never meet: with a lane per segment a wave is as slow as its slowest lane and two thirds of its lanes idle.
 	// Several segments per lane instead (the flat loop of spec_biquad_kernel hands a lane the next one): a
 	// eighth of the waves; at least 256 so that small batches keep their parallelism.
-	static const int repair_div = env_int("TFREC_AMD_REPAIR_DIV", 8, 1, 64);  // (256-slot segments: 6-8 measured equal; round 4 had 12 at 128 slots)
+	static const int repair_div = TFREC_KNOB_INT("REPAIR_DIV", 8, 1, 64);  // (256-slot segments: 6-8 measured equal; round 4 had 12 at 128 slots)
 	const int repair_blocks = std::min(seg_blocks, std::max(256, seg_blocks / repair_div));
 	// The speculative pass with a fifth of the worst-case waves (~830 at 1024 streams: 1-2 segments of 256 slots per lane).  A lane
 	// reads 64 (+4) bytes per slot at an arbitrary 2-byte offset of its row, so consecutive slots share a 128-byte line;
 	// with a lane per segment the lines in flight (2540 waves x 64 lanes x 2 lines = 40 MB) never survived in the 32 MB
 	// of L2 until the lane came back: the pass fetched 2.9 GB for 1.1 GB of input.  With ~1000 waves: 1.4 GB, and the
 	// batch 2 % shorter.  (A sixteenth starves the WHB chain.)
-	static const size_t lds_pad_spec = (size_t)env_int("TFREC_AMD_LDS_PAD_SPEC", 0, 0, 48 << 10);
-	static const int spec_div = env_int("TFREC_AMD_SPEC_DIV", 5, 1, 64);  // (256-slot segments: 4-6 measured equal, 3 and 8 worse; round 4 had 8 at 128 slots)
+	static const size_t lds_pad_spec = (size_t)TFREC_KNOB_INT("LDS_PAD_SPEC", 0, 0, 48 << 10);
+	static const int spec_div = TFREC_KNOB_INT("SPEC_DIV", 5, 1, 64);  // (256-slot segments: 4-6 measured equal, 3 and 8 worse; round 4 had 8 at 128 slots)
 	const int spec_blocks = std::min(seg_blocks, std::max(256, seg_blocks / spec_div));
 	// (few chains: the lanes of the lane-per-window kernels are mostly idle anyway and latency is all that counts)
-	static const int long_window_env = env_int("TFREC_AMD_COOP_MIN", 0, 0);
+	static const int long_window_env = TFREC_KNOB_INT("COOP_MIN", 0, 0, 1 << 30);
 	const int long_window = long_window_env >= 356 ? long_window_env
 						       : ((size_t)n_streams * L.n_active >= 1024 ? kLongWindow : kLongWindow / 2);
 	// long windows: at most M / long_window per chain
-	const int coop_blocks = std::min(env_int("TFREC_AMD_COOP_BLOCKS", 32768, 1, 1 << 20), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
+	const int coop_blocks = std::min(TFREC_KNOB_INT("COOP_BLOCKS", 32768, 1, 1 << 20), std::max(1, (int)std::min<size_t>((size_t)L.n_active * n_streams *
 								((size_t)n_blocks * kBlockDec / (size_t)std::max(long_window, 356) + 1), 1u << 30)));
 	const int dec_blocks = std::min(16384, std::max(1, win_blocks));
 	bool has_whb = false, has_tfa2 = false, has_tfa1 = false;
@@ -3983,7 +3997,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	int whb_verify = -1;  // the WHB slot, when its speculative stage 2 ran
 	// The discriminator pass (only the TFA_2 family reads its output) at the head of kw instead of k2: with the WHB stage 2
 	// speculated, k2 (discriminator + three biquad passes + verify) was the longest stream of the batch and kw half idle
-	static const int fmdev_kw = env_int("TFREC_AMD_FMDEV_KW", 0, 0, 1);  // (measured: 8.2 instead of 7.3 ms per batch -- the pass stretches to 5 ms there)
+	static const int fmdev_kw = TFREC_KNOB_INT("FMDEV_KW", 0, 0, 1);  // (measured: 8.2 instead of 7.3 ms per batch -- the pass stretches to 5 ms there)
 	const bool fm_on_kw = fmdev_kw && has_whb && has_tfa2 && P.fmdev_wmax > 0 && P.kw != P.k2;
 	if (has_whb) {
 		TRY(hipStreamWaitEvent(P.kw, P.ev_win, 0));
@@ -4018,12 +4032,12 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 				// chains' kernels occupy the chip, and its one-wave workgroups go wherever LDS is free: beside six resident
 				// front-end workgroups (25 KB each of the CU's 160 KB) the 17 KB it used to ask for did not fit at all, so it
 				// trickled onto the chip at the front end's pace.  TFREC_AMD_WHB_LDS raises it (caps the workgroups per CU).
-				static const int whb_lds = std::max(64 * 64, env_int("TFREC_AMD_WHB_LDS", 0, 0, 64 << 10));
+				static const int whb_lds = std::max(64 * 64, TFREC_KNOB_INT("WHB_LDS", 0, 0, 64 << 10));
 				const dim3 wgrid(n_streams), wblock(64);
 				const int wlds = whb_lds;
 				// TFREC_AMD_WHB_EXACT=1: the wave-per-stream recurrence (exact by itself: no verification pass).  BITS mode
 				// (parity / debug) uses it too.
-				static const int whb_exact = env_int("TFREC_AMD_WHB_EXACT", 0, 0, 1);
+				static const int whb_exact = TFREC_KNOB_INT("WHB_EXACT", 0, 0, 1);
 				if (whb_exact || (flags & TFREC_AMD_F_BITS)) {
 					hipLaunchKernelGGL((whb_demod_kernel<true, false>), wgrid, wblock, wlds, P.aux, dec, dec_stride, dev32, n_streams,
 							   n_blocks, sample_base, L, a, T, events, eb, flags);
@@ -4060,7 +4074,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 	} else {
 		TRY(hipEventRecord(P.done[1], P.aux));
 	}
-	static const int head_chunks = std::max(1, env_int("TFREC_AMD_HEAD_CHUNKS", 64));
+	static const int head_chunks = std::max(1, TFREC_KNOB_INT("HEAD_CHUNKS", 64, 0, 1 << 30));
 	// the slicer -> decoder chain of one protocol kind (0: TFA_1, 1: TFA_2 family) on stream s_
 	auto slicer_chain = [&](int kind, hipStream_t s_, int m0) {
 		if (kind == 0)
@@ -4069,10 +4083,10 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 					   n_blocks, L, T);
 		// The lanes take their windows from a queue, so the wave count is a free parameter: fewer waves = fewer registers
 		// held for milliseconds by a latency-bound kernel (the front end beside it lives on what is left), more windows per lane
-		static const int slicer_div = env_int("TFREC_AMD_SLICER_DIV", 1, 1, 64);
+		static const int slicer_div = TFREC_KNOB_INT("SLICER_DIV", 1, 1, 64);
 		// (TFREC_AMD_LDS_PAD_SLICER / _SPEC: sensitivity experiments -- extra dynamic LDS bytes per workgroup of the lane-per-window
 		// slicers / the biquad passes: how much of the period is these kernels' LDS footprint beside the front end's 16.6 KB tiles)
-		static const size_t lds_pad_slicer = (size_t)env_int("TFREC_AMD_LDS_PAD_SLICER", 0, 0, 48 << 10);
+		static const size_t lds_pad_slicer = (size_t)TFREC_KNOB_INT("LDS_PAD_SLICER", 0, 0, 48 << 10);
 		const size_t slds = (kind == 0 ? 8 : 4) * 64 * sizeof(uint4) + lds_pad_slicer;
 		const bool split = kind == 1 && P.cz != nullptr;
 		if (split) {
@@ -4138,7 +4152,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize + lds_pad_spec, P.k2, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
 		mark(2, P.k2);
-		if (has_tfa1 && !env_int("TFREC_AMD_T1_EARLY", 0)) {
+		if (has_tfa1 && !TFREC_KNOB_INT("T1_EARLY", 0, 0, 1 << 30)) {
 			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
 			// critical path of the other chains) has had the chip to itself
 			TRY(hipEventRecord(P.ev_fork, P.k2));

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "dsp_dev.h"
+#include "knobs.h"
 
 namespace tfrec {
 
@@ -529,7 +530,7 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 	const int m_total = n_blocks * kBlockDec;
 	dim3 grid(m_total / kTileDec, n_streams);
 	// experiment knob: extra dynamic LDS per workgroup (caps the front end's workgroups per CU)
-	static const int pad = getenv("TFREC_AMD_FE_LDS_PAD") ? atoi(getenv("TFREC_AMD_FE_LDS_PAD")) : 0;
+	static const int pad = TFREC_KNOB_INT("FE_LDS_PAD", 0, 0, 64 << 10);
 	if (in16)
 		hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kFrontThreads), pad, st, iq, stride, m_total, tail_in, tail_out,
 				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
