@@ -458,6 +458,12 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 				p.td_hi = (int)ceil(32 * p.spb) - 1;
 				p.iir = biquad_coef(0.5 / p.spb);  // tfa2.cpp:321
 			} else {
+				// whb_demod_kernel's candidate walk has the reference's 64 samples per bit (main.cpp:217) built in (chains2.hip: kWhbSpb)
+				if (p.spb != 64.0) {
+					snprintf(g_err, sizeof(g_err), "WHB chain with %.3f samples per bit: only 64 is built", p.spb);
+					rc = TFREC_AMD_E_INVAL;
+					break;
+				}
 				p.window = d2i_host(8 * p.spb);         // whb.cpp:641
 				p.iir = biquad_coef(2.0 / p.spb);       // whb.cpp:610
 				p.iir_avg = biquad_coef(0.0025 / p.spb); // whb.cpp:611

@@ -40,6 +40,7 @@
 
 #include "decoder_dev.h"
 #include "knobs.h"
+#include <type_traits>
 #include "whb_chain_asm.h"
 
 namespace tfrec {
@@ -2676,6 +2677,7 @@ __device__ __forceinline__ void whb_commit_stream(int s, int n_streams, int n_bl
 #define TFREC_AMD_WHB_AHEAD 1
 #endif
 constexpr int kWhbAhead = TFREC_AMD_WHB_AHEAD;  // whb_demod_kernel: steps whose stage-1 outputs are held ahead of the current one (one more is being loaded)
+constexpr int kWhbSpb = 64, kWhbSpbShift = 6;  // whb_demod's samples per bit (main.cpp:217), see whb_demod_kernel
 constexpr uint32_t kWhbSyncRev = 0xd2b42bd4u;  // bit-reversed 0x2bd42d4b (whb.cpp:582): newest bit at the LSB
 
 __device__ __forceinline__ int wave_shr1(int v)  // lane n <- lane n-1 (lane 0: 0)
@@ -2887,32 +2889,44 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		ChainState &st = L.states[a][s];
 		const double a1 = p.iir_avg.a1, a2 = p.iir_avg.a2;
 		const double bh = 0.5 * p.iir_avg.b0;  // t = fl(b0 * (0.5 * dev)) = fl((b0 / 2) * dev): scaling by two is exact
-		const double spb = p.spb;
-		const int tmin = (int)floor(3 * spb / 4) + 1;  // smallest integer tdiff with tdiff > 3*spb/4 (whb.cpp:664)
-		// (int)((tdiff + spb/2) / spb) is an exact shift when spb is a power of two (the reference's WHB: 64.0)
-		const int spb_i = (int)spb;
-		const bool spb_pow2 = (double)spb_i == spb && spb_i >= 2 && (spb_i & (spb_i - 1)) == 0;
-		const int spb_sh = 31 - __builtin_clz(spb_i > 0 ? spb_i : 1);
-		// ---- per-stream state, wave-uniform
+		// Samples per bit: the reference builds its one whb_demod with (1536000 / 4.0) / 6000 = 64.0 (main.cpp:217) and the
+		// C ABI has no other (capi.hip: reg[]; tfrec_amd_create rejects a WHB chain whose spb differs from kWhbSpb).  As a
+		// constant, (int)((tdiff + spb / 2) / spb) (whb.cpp:668) is a shift, "tdiff > 3 * spb / 4" (:664) is "tdiff >= 49",
+		// and a 64-sample step holds at most TWO accepted candidates, the second of which (tdiff in [49, 63]) emits one bit.
+		constexpr int tmin = 3 * kWhbSpb / 4 + 1;  // smallest integer tdiff with tdiff > 3*spb/4 (whb.cpp:664)
+		static_assert(kWhbSpb == 64 && (1 << kWhbSpbShift) == kWhbSpb && tmin > kStep / 2 && (kStep - 1 + kWhbSpb / 2) >> kWhbSpbShift == 1,
+			      "the candidate walk knows two candidates per step, the second one bit long");
+		// ---- per-stream state, wave-uniform.  The state arrives through vector loads; v_readfirstlane moves what the
+		// candidate walk computes with into scalar registers (round 6: the compiler kept `synced`, the byte counters and
+		// the descrambler history in vector registers and paid a vector compare + branch on vcc for every test of them)
+		auto sgpr = [](int v) -> int { return __builtin_amdgcn_readfirstlane(v); };
+		auto sgpr64 = [](long long v) -> long long {
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unsigned long long)v);
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32));
+			return (long long)(((unsigned long long)hi << 32) | lo);
+		};
 		double y1 = st.iir_avg.yn, y2 = st.iir_avg.yn1;  // iir_avg: its last two outputs ...
 		// ... and its last two inputs: 0.5 * (a stage-1 output) each, carried as the integers
-		int fd1 = (int)(2.0 * st.iir_avg.dn1), fd2 = (int)(2.0 * st.iir_avg.dn2);
-		int avg_of = st.avg_of, last_dev = st.last_dev;
-		long long step0 = (long long)st.step;               // samples since the window opened, at the window's first sample here
-		long long since = step0 - (long long)st.last_peak;  // ... since the last accepted candidate, at the step's first sample
+		int fd1 = sgpr((int)(2.0 * st.iir_avg.dn1)), fd2 = sgpr((int)(2.0 * st.iir_avg.dn2));
+		int avg_of = sgpr(st.avg_of), last_dev = sgpr(st.last_dev);
+		long long step0 = sgpr64((long long)st.step);               // samples since the window opened, at the window's first sample here
+		// ... since the last accepted candidate, at the step's first sample: `int tdiff = step - last_peak` (whb.cpp:659) keeps
+		// the low 32 bits of the difference, and so does this (unsigned: the additions may wrap)
+		uint32_t since = (uint32_t)sgpr((int)(uint32_t)(st.step - st.last_peak));
 		// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
 		// additions are exact in any order: every lane adds its samples' power, the wave sums once per window.
 		double rssi_d = st.rssi_d;    // rssi collected in earlier submits of a still-open window
 		unsigned long long racc = 0;  // ... and in this submit (per lane)
-		int synced = st.synced;
+		int synced = sgpr(st.synced);
 		// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
 		// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
-		uint32_t srr = __brev(st.sr);  // whb_decoder::sr, newest bit at the LSB
-		uint32_t nh = st.lfsr;         // history of nrzs, newest at the LSB (whb.cpp:579)
-		const uint32_t kmask = (st.nrzs ^ st.w_last_bit) & 1 ? ~0u : 0u;
+		uint32_t srr = (uint32_t)sgpr((int)__brev(st.sr));  // whb_decoder::sr, newest bit at the LSB
+		const uint32_t kmask = (uint32_t)sgpr((st.nrzs ^ st.w_last_bit) & 1 ? -1 : 0);
+		// history of the emitted BITS, newest at the LSB: whb_decoder::lfsr (the history of nrzs, whb.cpp:579) is bhist ^ kmask
+		uint32_t bhist = (uint32_t)sgpr((int)st.lfsr) ^ kmask;
 		// sr_cnt / byte_cnt while the decoder has not locked since its last flush (they only matter before a stream's
 		// first flush, when the zero-initialised sr_cnt = 0 lets store_bit count bytes without a sync word)
-		int sc = st.sr_cnt, bc = st.byte_cnt;
+		int sc = sgpr(st.sr_cnt), bc = sgpr(st.byte_cnt);
 		const bool cont = T.cont[c] != 0;
 		// EXACT = false: the filter's steps are evaluated lane-parallel (whb_scan_step) and their decisions recorded for
 		// whb_verify_kernel: one word per step in which the filter ran, numbered through the submit
@@ -2929,42 +2943,38 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		WhbStepRec *const recrow = T.whbrec + (size_t)s * T.whbrec_stride;
 		int vstep = 0;
 
-		// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word
+		// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word.
+		// The descrambled bit is nrzs(t) ^ nrzs(t-12) ^ nrzs(t-17) (whb.cpp:578) = b(t) ^ b(t-12) ^ b(t-17) ^ K.
 		auto feed = [&](uint32_t e, int len) -> bool {
 			const uint32_t emask = len >= 32 ? ~0u : (1u << len) - 1u;
-			const uint32_t nrun = __brev((e ^ kmask) & emask) >> (32 - len);         // nrzs of the run, newest at the LSB
-			const unsigned long long hn = ((unsigned long long)nh << len) | nrun;
-			const uint32_t orun = (uint32_t)(hn ^ (hn >> 12) ^ (hn >> 17)) & emask;  // descrambled bits, whb.cpp:578
+			const uint32_t brun = __brev(e & emask) >> (32 - len);                   // the run's bits, newest at the LSB
+			const unsigned long long hb = ((unsigned long long)bhist << len) | brun;
+			const uint32_t orun = ((uint32_t)(hb ^ (hb >> 12) ^ (hb >> 17)) ^ kmask) & emask;  // descrambled bits
 			const unsigned long long sv = ((unsigned long long)srr << len) | orun;
 			const bool hit = ln < len && (uint32_t)(sv >> (len - 1 - (ln < len ? ln : 0))) == kWhbSyncRev;
-			nh = (uint32_t)hn;
+			bhist = (uint32_t)hb;
 			srr = (uint32_t)sv;
 			return __ballot(hit) != 0ull;
-		};
-		// the run "0,1,1,.." of `len` bits through the sync search (cut to its first 160 bits: the registers reach a
-		// fixed point after 17 + 32 equal bits)
-		auto feed_run = [&](int len) -> bool {
-			bool hit = feed(~1u, len < 32 ? len : 32);
-			for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
-				hit = feed(~0u, rest < 32 ? rest : 32) || hit;
-			return hit;
 		};
 
 		for (int j = 0; j < count; j++) {
 			// ---- the window
-			const int og = T.open[(size_t)c * T.cap + j];
-			const int close = T.close[(size_t)c * T.cap + j];
+			const int og = sgpr(T.open[(size_t)c * T.cap + j]);
+			const int close = sgpr(T.close[(size_t)c * T.cap + j]);
 			const bool closed = close < M;
 			const int n = (closed ? close : M - 1) - og + 1;
 			const int nch = (n + kStep - 1) / kStep;
 			const int slot0 = win_slot0(og, j);
-			const int32_t *wp = dvrow + (size_t)slot0 * 32 + ln;  // the lane's stage-1 output of step 0
+			// the stage-1 outputs of the window's step 0 (a wave-uniform pointer: the loads take it as their scalar base and the
+			// lane as their offset)
+			const int32_t *wq = dvrow + (size_t)slot0 * 32;
 			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
 			// kWhbAhead steps stay in flight (past the window's end: the row's next slots or the slack behind it, never used)
-			int cur = wp[0], nxt[kWhbAhead];
+			int cur = wq[ln], nxt[kWhbAhead];
 #pragma unroll
 			for (int k = 0; k < kWhbAhead; k++)
-				nxt[k] = wp[kStep * (k + 1)];
+				nxt[k] = wq[kStep * (k + 1) + ln];
+			wq += kStep * (kWhbAhead + 1);  // the step the loop loads next
 			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
 				racc = 0;
@@ -2979,21 +2989,20 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			if (ln == 0) {
 				WhbStart ws;
 				ws.sr = __brev(srr);
-				ws.lfsr = nh;
+				ws.lfsr = bhist ^ kmask;
 				ws.sr_cnt = sc;
 				ws.byte_cnt = bc;
 				ws.synced = synced;
 				ws.pad_[0] = ws.pad_[1] = ws.pad_[2] = 0;
 				T.whbstart[(size_t)s * T.cap + j] = ws;
 			}
-			// run lengths of the accepted candidates: entry q of the window sits in lane q & 63 until 64 are complete
+			// run lengths of the accepted candidates, one uint16 entry each, stored as they are produced: every lane stores the
+			// same value to the same address (rounds 3-5 collected 64 of them in a lane register first: a vector compare, a
+			// select and a test of the counter per entry)
 			int nent = 0;
-			uint32_t entbuf = 0;
 			auto put_ent = [&](uint32_t v16) {
-				entbuf = ln == (nent & 63) ? v16 : entbuf;
+				ent[nent] = (uint16_t)v16;
 				nent++;
-				if ((nent & 63) == 0)
-					ent[nent - 64 + ln] = (uint16_t)entbuf;
 			};
 			// the lane's decimated sample of this step and the next (rssi: only while the decoder is locked)
 			auto iq_load = [&](int i) -> uint32_t {
@@ -3008,11 +3017,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			for (int i = 0; i < nch; i++) {
 				// ---- (1) this step's inputs; the next two steps' are in flight
 				const int nv = n - kStep * i < kStep ? n - kStep * i : kStep;
-				const int nxn = wp[kStep * (i + kWhbAhead + 1)];
+				const unsigned long long valid = nv < kStep ? (1ull << nv) - 1ull : ~0ull;  // the step's samples inside the window
+				const int nxn = wq[ln];
+				wq += kStep;
 				const int dev = cur;
 				const int sh1 = wave_shr1(dev);
 				const int devm1 = ln == 0 ? last_dev : sh1;  // dev > last_dev (whb.cpp:663): the sample before the step
-				const bool rise = dev > devm1;
+				const unsigned long long rise_m = __builtin_amdgcn_ballot_w64(dev > devm1) & valid;
 				const bool was_synced = synced != 0;
 				unsigned long long mask;
 				const double y1_in = y1;
@@ -3073,7 +3084,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 #endif
 					}
 					// |0.5*dev| <= 6.6e8 and the decision-level low-pass has an L1 gain of 1.09: (int) never saturates
-					const unsigned long long below = __ballot(ln < nv && dev < (int)ym);
+					const unsigned long long below = __builtin_amdgcn_ballot_w64(dev < (int)ym) & valid;
 					if (!EXACT) {
 						if (ln == 0) {  // (where the decoder locks in this step, the window's end rewrites meta and avgf)
 							WhbStepRec r;
@@ -3084,38 +3095,52 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 						}
 						vstep++;
 					}
-					mask = below & __ballot(rise);
+					mask = below & rise_m;
 				} else {
-					mask = __ballot(ln < nv && dev < avg_of && rise);
+					mask = __builtin_amdgcn_ballot_w64(dev < avg_of) & rise_m;
 					if (!EXACT)
-						amb = amb || __ballot(ln < nv && rise && (uint32_t)(avg_of + amb_lo - dev) < amb_w) != 0ull;
+						amb = amb || (__builtin_amdgcn_ballot_w64((uint32_t)(avg_of + amb_lo - dev) < amb_w) & rise_m) != 0ull;
 				}
 				// ---- (4) accepted candidates
 				int locked_at = -1;
-				while (mask) {
-					const long long kmin = (long long)tmin - since;  // first k with tdiff > 3*spb/4
-					if (kmin > kStep - 1)
-						break;
-					if (kmin > 0)
-						mask &= ~0ull << (int)kmin;
-					if (!mask)
-						break;
-					const int k = __builtin_ctzll(mask);
-					mask &= mask - 1;
-					const int tdiff = (int)(since + k);
+				// one accepted candidate at sample k of the step, tdiff samples after the one before it (whb.cpp:665-674);
+				// ONE = std::true_type: the step's second candidate, whose run is one bit long
+				auto pulse = [&](const int k, const int tdiff, auto ONE) {
+					constexpr bool one = decltype(ONE)::value;
 					// whb.cpp:666-673: one 0, then (bit0 - 1) ones
-					const int bit0 = spb_pow2 ? (tdiff + (spb_i >> 1)) >> spb_sh : d2i((tdiff + spb / 2) / spb);
+					const int bit0 = one ? 1 : (tdiff + kWhbSpb / 2) >> kWhbSpbShift;
 					const int len = bit0 > 1 ? bit0 : 1;
-					if (len < kWhbRunEsc) {
+					if (one || len < kWhbRunEsc) {
 						put_ent((uint32_t)len);
 					} else {
 						put_ent((uint32_t)kWhbRunEsc);
 						put_ent((uint32_t)len & 0xffffu);
 						put_ent((uint32_t)len >> 16);
 					}
-					const bool hit = feed_run(len);
-					since = -(long long)k;  // last_peak = this sample
-					if (!synced) {
+					// The run "0,1,1,.." joins the bit history, in scalar registers (its first 32 bits; the ones beyond are the rare
+					// tail below).  The sync search -- only while the decoder is unsynced: once it has locked, a second hit of the
+					// sync word matters to the decoder stage alone, which replays the runs bit by bit -- looks at the run's
+					// positions one per lane.
+					const int l0 = one ? 1 : (len < 32 ? len : 32);
+					const unsigned long long hb = ((unsigned long long)bhist << l0) | ((1ull << (l0 - 1)) - 1ull);
+					bool hit = false;
+					if (synced == 0) {
+						const uint32_t emask = (uint32_t)((1ull << l0) - 1ull);
+						const uint32_t orun = ((uint32_t)hb ^ (uint32_t)(hb >> 12) ^ (uint32_t)(hb >> 17) ^ kmask) & emask;
+						const unsigned long long sv = ((unsigned long long)srr << l0) | orun;
+						if (one) {
+							hit = (uint32_t)sv == kWhbSyncRev;
+						} else {  // lane l < l0: sr after all but the run's last l bits
+							const unsigned long long hits = __builtin_amdgcn_ballot_w64((uint32_t)(sv >> ln) == kWhbSyncRev);
+							hit = (hits & (unsigned long long)emask) != 0ull;
+						}
+						srr = (uint32_t)sv;
+					}
+					bhist = (uint32_t)hb;
+					if (!one && len > 32)  // (cut to the run's first 160 bits: the registers reach a fixed point after 17 + 32 equal bits)
+						for (int rest = (len > 160 ? 160 : len) - 32; rest > 0; rest -= 32)
+							hit = feed(~0u, rest < 32 ? rest : 32) || hit;
+					if (synced == 0) {
 						if (sc >= 0) {  // sr_cnt / byte_cnt over `len` bits without a sync word (whb.cpp:590-596)
 							const int i0 = (8 - sc) & 7;  // first bit of the run that finds sr_cnt == 0
 							bc += i0 < len ? (len - 1 - i0) / 8 + 1 : 0;
@@ -3135,9 +3160,29 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 							lock_pos = kStep * i + k;
 							avg_frozen = avg_of;
 							// the rest of the step's candidates against the frozen avg_of
-							mask = __ballot(ln < nv && ln > k && dev < avg_of && rise);
+							const unsigned long long after = k < kStep - 1 ? ~0ull << (k + 1) : 0ull;
+							mask = __builtin_amdgcn_ballot_w64(dev < avg_of) & rise_m & after;
 							if (!EXACT)
-								amb = amb || __ballot(ln < nv && ln > k && rise && (uint32_t)(avg_of + amb_lo - dev) < amb_w) != 0ull;
+								amb = amb || (__builtin_amdgcn_ballot_w64((uint32_t)(avg_of + amb_lo - dev) < amb_w) & rise_m & after) != 0ull;
+						}
+					}
+				};
+				if (mask) {
+					// first k with tdiff = since + k > 3*spb/4 (whb.cpp:664), in the reference's int arithmetic
+					// (a difference that has wrapped to a negative int accepts nothing, as in the reference)
+					const int kmin = (int)since < -kStep ? kStep : tmin - (int)since;
+					const unsigned long long m1 = kmin > 0 ? (kmin > kStep - 1 ? 0ull : mask & (~0ull << kmin)) : mask;
+					if (m1) {
+						const int k = __builtin_ctzll(m1);
+						pulse(k, (int)(since + (uint32_t)k), std::false_type{});
+						since = (uint32_t)-k;  // last_peak = this sample
+						const int k2min = k + tmin;
+						// (`mask` again: a lock at k replaced it by the tests against the frozen average)
+						const unsigned long long m2 = k2min > kStep - 1 ? 0ull : mask & (~0ull << k2min);
+						if (m2) {
+							const int k2 = __builtin_ctzll(m2);
+							pulse(k2, k2 - k, std::true_type{});
+							since = (uint32_t)-k2;
 						}
 					}
 				}
@@ -3156,7 +3201,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					avg_of = (int)y1;
 				}
 				last_dev = dl1;
-				since += nv;
+				since += (uint32_t)nv;
 				if (synced) {  // whb.cpp:677-678: from the sample at which the decoder locked on
 					uint32_t w = iq0;
 					if (locked_at >= 0) {
@@ -3179,9 +3224,6 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 #endif
 			}
 			// ---- the window's last sample in this submit
-			if (nent & 63)
-				if (ln < (nent & 63))
-					ent[(nent & ~63) + ln] = (uint16_t)entbuf;
 			WinResult res;
 			res.nbits = nent;
 			res.closed = 0;
