@@ -201,6 +201,11 @@ int tfrec_amd_atan_uncertain(tfrec_amd_ctx *ctx, uint64_t *n);
  * reaches; kind 2: the device's fm_dev_nrzs (dsp_stuff.cpp:269-279, with its +-1e9 clamp) on int32 quadruples.
  * out[n].  No context needed.  stats (may be NULL): as above, for this call. */
 int tfrec_amd_fm_dev_probe(int device, int kind, const void *records, size_t n, int32_t *out, tfrec_amd_fm_stats *stats);
+/* Parity probe: the device's iir2 (dsp_stuff.cpp:28-56: set(cutoff), then step() over in[0 .. n) from the zero state) ->
+ * out[n], the outputs as doubles, bit for bit what the reference's normative build produces.  form 0:
+ * the step as the reference associates it; form 1: the 3-multiply form the biquad passes and WHB stage 2 run (csrc/dsp_dev.h:
+ * iir_step_t).  cutoff: iir2's argument, e.g. 0.5 / spb (tfa2.cpp:321), 2.0 / 64, 0.0025 / 64 (whb.cpp:610-611).  No context. */
+int tfrec_amd_iir_probe(int device, double cutoff, int form, const double *in, size_t n, double *out);
 int tfrec_amd_get_timings(tfrec_amd_ctx *ctx, tfrec_amd_timings *out);
 /* Cumulative counters of the speculative stages (window-parallel pipeline only).  They only describe how the work
  * was done -- results do not depend on them. */

@@ -400,6 +400,21 @@ def test_fm_dev_next_to_truncation_boundaries_equals_the_real_reference(golden_d
     assert np.array_equal(got, u["fm_out"][:, 0]) and st["host_mismatch"] == 0
 
 
+@pytest.mark.parametrize("form", [0, 1])
+def test_iir2_probe_equals_the_real_reference_bit_for_bit(golden_dir, form):
+    """iir2::set / iir2::step (dsp_stuff.cpp:28-56) by themselves: the device's biquad -- as the reference associates the step
+    (form 0) and in the 3-multiply form every biquad pass and WHB stage 2 run (form 1) -- over the 4000-sample probe sequence,
+    for the five cut-offs the reference instantiates (main.cpp:186-217, tfa2.cpp:321, whb.cpp:610-611), against outputs of the
+    REAL reference (oracle/mint_golden.py: unit_probes.npz).  The pipeline tests see the biquads only through the integers
+    behind them; this one localises a failure."""
+    import os
+
+    u = np.load(os.path.join(golden_dir, "unit_probes.npz"))
+    for k, cutoff in enumerate(u["iir_cutoffs"]):
+        y = api.iir_probe(float(cutoff), u["iir_in"], form=form)
+        assert np.array_equal(y.view(np.uint64), u["iir_out"][k].view(np.uint64)), "cutoff %r form %d" % (cutoff, form)
+
+
 @pytest.mark.parametrize("eps", ["1e-4", "1e-3", "0.6"])
 def test_fm_dev_slow_path_through_the_pipeline(eps, monkeypatch):
     """The exact slow path decides the same integer as the fast path wherever the fast path is certain, so widening

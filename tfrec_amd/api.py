@@ -89,7 +89,7 @@ EXPORTS = (
     "tfrec_amd_pending_events", "tfrec_amd_rssi_db", "tfrec_amd_read_decimated", "tfrec_amd_atan_uncertain",
     "tfrec_amd_get_timings", "tfrec_amd_read_thresh", "tfrec_amd_get_stats", "tfrec_amd_get_layout", "tfrec_amd_host_alloc",
     "tfrec_amd_host_free", "tfrec_amd_read_stage0", "tfrec_amd_get_fm_stats", "tfrec_amd_fm_dev_probe",
-    "tfrec_amd_fifo_depth", "tfrec_amd_get_memory",
+    "tfrec_amd_fifo_depth", "tfrec_amd_get_memory", "tfrec_amd_iir_probe",
 )
 
 _libs = {}
@@ -146,6 +146,7 @@ def load_library(build: bool = True, experiments: bool = False):
     L.tfrec_amd_get_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.tfrec_amd_get_fm_stats.argtypes = [C.c_void_p, C.POINTER(FmStats)]
     L.tfrec_amd_fm_dev_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(FmStats)]
+    L.tfrec_amd_iir_probe.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     L.tfrec_amd_fifo_depth.restype = C.c_int
     if L.tfrec_amd_fifo_depth() != FIFO_DEPTH:
         raise RuntimeError("libtfrec_amd.so was built with FIFO depth %d, this binding expects %d" % (
@@ -298,6 +299,16 @@ def fm_dev_nrzs_probe(records: np.ndarray, device: int = 0) -> np.ndarray:
     q = np.ascontiguousarray(records, dtype=np.int32).reshape(-1, 4)
     out = np.empty(len(q), dtype=np.int32)
     _check(L, L.tfrec_amd_fm_dev_probe(device, 2, q.ctypes.data, len(q), out.ctypes.data, None))
+    return out
+
+
+def iir_probe(cutoff: float, x: np.ndarray, form: int = 1, device: int = 0) -> np.ndarray:
+    """The device's iir2 (dsp_stuff.cpp:28-56) with set(cutoff) over the doubles x from the zero state -> float64[n].
+    form 0: iir_step (the reference's association), form 1: iir_step_t (the form the kernels run)."""
+    L = load_library()
+    xin = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(len(xin), dtype=np.float64)
+    _check(L, L.tfrec_amd_iir_probe(device, float(cutoff), int(form), xin.ctypes.data, len(xin), out.ctypes.data))
     return out
 
 

@@ -26,6 +26,7 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			   long long sample_base, const ChainLaunch &L, const WinTables &T, int16_t *ld16, int32_t *dev32,
 			   tfrec_amd_event *events, EventBuf *eb, uint32_t flags);
 hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32_t *out, EventBuf *eb, int kind);
+hipError_t launch_iir_probe(hipStream_t st, const double *in, size_t n, const BiquadCoef &c, double *out, int form);
 hipError_t launch_threshold(hipStream_t st, const uint32_t *dec, size_t dec_stride, unsigned long long *mask,
 			    size_t mask_stride, int n_streams, int n_blocks, FskState *fsk, int wmax);
 hipError_t launch_chains(hipStream_t st, const uint32_t *dec, size_t dec_stride, const unsigned long long *mask,
@@ -1282,6 +1283,24 @@ int tfrec_amd_fm_dev_probe(int device, int kind, const void *quads_v, size_t n, 
 		stats->host_mismatch = tmp.mismatch;
 		stats->undecidable = tmp.undecidable;
 	}
+	return rc;
+}
+
+int tfrec_amd_iir_probe(int device, double cutoff, int form, const double *in, size_t n, double *out)
+{
+	if (!in || !out || n == 0 || n > (1u << 24) || form < 0 || form > 1 || !(cutoff > 0.0 && cutoff < 0.5))
+		return TFREC_AMD_E_INVAL;
+	HIPCHK(hipSetDevice(device));
+	double *d_in = nullptr, *d_out = nullptr;
+	int rc = TFREC_AMD_OK;
+	if (hipMalloc((void **)&d_in, n * 8) != hipSuccess || hipMalloc((void **)&d_out, n * 8) != hipSuccess)
+		rc = TFREC_AMD_E_NOMEM;
+	if (rc == TFREC_AMD_OK && (hipMemcpy(d_in, in, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+				   launch_iir_probe(nullptr, d_in, n, biquad_coef(cutoff), d_out, form) != hipSuccess ||
+				   hipMemcpy(out, d_out, n * 8, hipMemcpyDeviceToHost) != hipSuccess))
+		rc = hip_fail(hipGetLastError(), "iir_probe");
+	(void)hipFree(d_in);
+	(void)hipFree(d_out);
 	return rc;
 }
 

@@ -561,6 +561,30 @@ __global__ __launch_bounds__(256) void fm_probe_kernel(const int32_t *__restrict
 	}
 }
 
+// Parity probe (tfrec_amd_iir_probe): iir2::step (dsp_stuff.cpp:47-56) over a sequence of doubles from the zero state, one
+// lane, in the two forms the kernels use -- form 0: iir_step, the reference's association as written; form 1: iir_step_t, the
+// 3-multiply form of the biquad passes and of WHB stage 2 (dsp_dev.h).  Both must reproduce the reference bit for bit.
+__global__ __launch_bounds__(64) void iir_probe_kernel(const double *__restrict__ in, size_t n, BiquadCoef c, double *__restrict__ out, int form)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0)
+		return;
+	Biquad f = { 0.0, 0.0, 0.0, 0.0 };
+	if (form == 0) {
+		for (size_t k = 0; k < n; k++)
+			out[k] = iir_step(f, c, in[k]);
+	} else {
+		BiquadT t = iirt_enter(f, c);
+		for (size_t k = 0; k < n; k++)
+			out[k] = iir_step_t(f, t, c, in[k]);
+	}
+}
+
+hipError_t launch_iir_probe(hipStream_t st, const double *in, size_t n, const BiquadCoef &c, double *out, int form)
+{
+	hipLaunchKernelGGL(iir_probe_kernel, dim3(1), dim3(64), 0, st, in, n, c, out, form);
+	return hipGetLastError();
+}
+
 hipError_t launch_fm_probe(hipStream_t st, const int32_t *quads, size_t n, int32_t *out, EventBuf *eb, int kind)
 {
 	hipLaunchKernelGGL(fm_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, quads, n, out, eb, kind);
