@@ -91,8 +91,9 @@ struct tfrec_amd_ctx {
 	bool scan_on_kw = false;                      // deep layout: the window scan runs at the head of kw, not on fs
 	bool fmdev_k2 = false;                        // the discriminator pass runs at the head of k2, not behind the front end
 	hipEvent_t ev_in[kSets] = {}, ev_front[kSets] = {};
-	hipEvent_t ev_pipe[kSets][7] = {};
+	hipEvent_t ev_pipe[kSets][8] = {};
 	hipStream_t fq = nullptr;                    // PipeCtl::fq (TFREC_AMD_FMDEV_OWN)
+	hipStream_t ks = nullptr;                    // PipeCtl::ks (TFREC_AMD_SPEC_OWN)
 	hipStream_t cq = nullptr;                    // the drain's copies, when not on cp (TFREC_AMD_COPY_OWN)
 	hipStream_t cz = nullptr;                    // PipeCtl::cz (TFREC_AMD_COOP_STREAM)                // per set: window scan done, TFA_1 fork, TFA_2 / WHB biquads done
 	int last_set = 0;
@@ -315,6 +316,8 @@ int tfrec_amd_destroy(tfrec_amd_ctx *c)
 		(void)hipStreamDestroy(c->cz);
 	if (c->fq)
 		(void)hipStreamDestroy(c->fq);
+	if (c->ks)
+		(void)hipStreamDestroy(c->ks);
 	if (c->cq)
 		(void)hipStreamDestroy(c->cq);
 	(void)hipFree(c->d_whbx);
@@ -589,6 +592,11 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		const size_t o_wrec = carve(whb ? n * (size_t)T.whbrec_stride * sizeof(WhbStepRec) : 0), o_wfail = carve(whb ? n * 4 : 0);
 		const size_t o_wsnap = carve(whb ? n * sizeof(ChainState) : 0), o_wx0 = carve(whb ? n * sizeof(WhbExact) : 0);
 		const size_t o_wseen = carve(whb ? n * 4 : 0);
+		T.whbdense_stride = (int32_t)(m_max + 64);
+		T.whbx_stride = (int32_t)(m_max / 64 + 2);
+		const size_t o_wdn = carve(whb ? n * 4 : 0), o_wxb = carve(whb ? n * (size_t)T.whbx_stride * 8 : 0);
+		const size_t o_wxs = carve(whb ? n * (size_t)T.whbx_stride * sizeof(double2) : 0);
+		const size_t o_wdense = carve(whb ? n * (size_t)T.whbdense_stride * 4 : 0);
 		ALLOC(c->win_block[set], off);
 		if (rc == TFREC_AMD_OK) {
 			uint8_t *b = (uint8_t *)c->win_block[set];
@@ -620,6 +628,10 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			T.whbsnap = (ChainState *)(b + o_wsnap);
 			T.whbx0 = (WhbExact *)(b + o_wx0);
 			T.whbseen = (uint32_t *)(b + o_wseen);
+			T.whbdense = (int32_t *)(b + o_wdense);
+			T.whbdense_n = (int32_t *)(b + o_wdn);
+			T.whbxbits = (unsigned long long *)(b + o_wxb);
+			T.whbxsnap = (double2 *)(b + o_wxs);
 			T.whbgen = c->d_whbgen;
 			T.whbX = c->d_whbX;
 			T.whbscr = c->d_whbscr;
@@ -750,6 +762,16 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 			const int m = TFREC_KNOB_INT("FMDEV_OWN", c->fmdev_k2 ? 1 : 0, 0, 3);
 			if (c->deep && rc == TFREC_AMD_OK && m > 0 && c->need_fmdev && c->fmdev_k2 &&
 			    hipStreamCreateWithPriority(&c->fq, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
+				rc = TFREC_AMD_E_HIP;
+		}
+		// The speculative biquad pass of the TFA_2 family on a stream of its own (TFREC_AMD_SPEC_OWN: 0 = at the head of k2,
+		// 1 = low priority (default when the discriminator pass has its stream), 2 = normal, 3 = high): it needs nothing of the
+		// submit before (chains2.hip K3a), so it runs beside that submit's repair passes and chain walk on k2.  The third
+		// stream of the low-priority pool (with fq and cq): no shared hardware queue.
+		{
+			const int m = TFREC_KNOB_INT("SPEC_OWN", 1, 0, 3);
+			if (c->deep && rc == TFREC_AMD_OK && m > 0 && c->fq &&
+			    hipStreamCreateWithPriority(&c->ks, hipStreamNonBlocking, m == 1 ? prio_lo : (m == 2 ? 0 : prio_hi)) != hipSuccess)
 				rc = TFREC_AMD_E_HIP;
 		}
 		// The drain's copy on a low-priority stream of its own (TFREC_AMD_COPY_OWN=0: on cp).  On cp it sat between the WHB
@@ -883,6 +905,8 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 		P.ev_fm = c->ev_pipe[set][4];
 		P.cz = c->cz;
 		P.fq = c->fq;
+		P.ks = c->ks;
+		P.ev_spec = c->ev_pipe[set][7];
 		P.ev_heads = c->ev_pipe[set][5];
 		P.ev_coop = c->ev_pipe[set][6];
 		for (int k = 0; k < 3; k++)
@@ -1072,7 +1096,7 @@ int tfrec_amd_sync(tfrec_amd_ctx *c)
 	if (!c)
 		return TFREC_AMD_E_INVAL;
 	HIPCHK(hipSetDevice(c->cfg.device));
-	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->fq, c->cq, c->aux, c->vx, c->t1, c->cp })
+	for (hipStream_t st : { c->fs, c->k2, c->kw, c->cs, c->cz, c->fq, c->ks, c->cq, c->aux, c->vx, c->t1, c->cp })
 		if (st)
 			HIPCHK(hipStreamSynchronize(st));
 	return TFREC_AMD_OK;

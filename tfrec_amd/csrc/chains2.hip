@@ -419,11 +419,13 @@ struct ChunkIter {
 // trajectory after a few hundred samples, and once the full state (yn, yn1 + the two last inputs) matches
 // bit for bit it matches forever.  The in-window slots of a chain, numbered consecutively across windows, are
 // cut into segments of kSegSlots slots (>= 3700 samples), and
-//   K3a spec_biquad_kernel   lane per SEGMENT (work queue): runs the segment from a zero state (the chain's
-//                            first segment from the true carried state), stores the truncated outputs the
-//                            slicers consume, a (yn, yn1) checkpoint per slot and the full end state;
+//   K3a spec_biquad_kernel   lane per SEGMENT (work queue): runs the segment from a zero state (every segment, the
+//                            chain's first too: the pass needs nothing of the submit before and runs on a stream of
+//                            its own, PipeCtl::ks), stores the truncated outputs the slicers consume, a (yn, yn1)
+//                            checkpoint per slot and the full end state;
 //   K3b repair_biquad_kernel lane per SEGMENT: runs the head of the segment again, now from the END state of
-//                            the previous segment's speculative run, rewriting the outputs until its state
+//                            the previous segment's speculative run (the chain's first segment: from the true
+//                            carried state), rewriting the outputs until its state
 //                            equals the speculative checkpoint bit for bit -- from there on the stored outputs
 //                            are the continuation of THIS run;
 //   K3c fix_biquad_kernel    lane per CHAIN: walks the segments in order with the true state f.  If f equals the
@@ -716,16 +718,17 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 				f.dn1 = f.dn2 = f.yn = f.yn1 = 0.0;
 				min_slots = 0;
 				if (MODE == 0) {
-					if (k == 0)
-						f = L.states[a][s].iir;  // the chain's first segment starts from the true carried state
+					// EVERY segment from a zero state, the chain's first one too (until round 5 it started from the carried state,
+					// which the chain walk of the submit before writes: the pass of submit k + 1 then had to wait for it and
+					// sat on the TFA_2 family's serial stage loop; now it needs the discriminator pass and the window scan only)
 				} else if (MODE == 1) {
-					run = k > 0;
-					if (run)
-						f = biquad_of(T.segend1[sk - 1]);
+					// segment 0 from the TRUE carried state (this pass runs behind the chain walk of the submit before),
+					// segment k > 0 from the speculative end of k - 1
+					f = k > 0 ? biquad_of(T.segend1[sk - 1]) : L.states[a][s].iir;
 				} else {
 					// the run K3b made for segment k started from the speculative end of k-1; if K3b's own run of k-1 was
 					// the true one, its end state segend2[k-1] is where segment k really starts
-					run = k > 1 && !(T.segfix[sk - 1] & kSegConverged);
+					run = k > 0 && !(T.segfix[sk - 1] & kSegConverged);
 					if (run) {
 						f = biquad_of(T.segend2[sk - 1]);
 						min_slots = T.segfix[sk] & ~kSegConverged;
@@ -854,8 +857,7 @@ __device__ __forceinline__ void fix_chain(int a, int s, int n_streams, int M, co
 	const double2 *ckrow = T.ckpt + (size_t)(c - T.ck_c0) * T.slots;
 	// the end state of segment kk, IF the last run that wrote it started from the true state
 	auto end_if_good = [&](int kk) -> BiquadEnd {
-		if (kk == 0)
-			return e1[0];  // the speculative run of segment 0 starts from the carried state
+		// (segment 0: its repair run K3b started from the carried state, which is the true one)
 		const size_t sk = (size_t)c * T.segcap + kk;
 		const int fx2 = T.segfix2[sk];
 		const bool second = (fx2 & kSegRan) != 0;
@@ -2942,6 +2944,10 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		const uint32_t amb_w = 2u * (uint32_t)amb_tol;
 		WhbStepRec *const recrow = T.whbrec + (size_t)s * T.whbrec_stride;
 		int vstep = 0;
+		// ... and the filter's input sequence (whb_check.h: the exact chain walks it a stream per lane): the stage-1 outputs of
+		// the samples the average ran on, in order, behind each other
+		int32_t *const dense = T.whbdense + (size_t)s * T.whbdense_stride;
+		int dcount = 0;
 
 		// feed `len` emitted bits (bit i of `e` = i-th bit, len <= 32) to the sync search; true if sr hit the sync word.
 		// The descrambled bit is nrzs(t) ^ nrzs(t-12) ^ nrzs(t-17) (whb.cpp:578) = b(t) ^ b(t-12) ^ b(t-17) ^ K.
@@ -3032,19 +3038,32 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				pf_steps++;
 				pf_mark = __builtin_readcyclecounter();
 #endif
-				if (!was_synced) {
-					// ---- (2) feed-forward half of iir2::step for the lane's sample (see iir_step_t)
-					const int devm1f = ln == 0 ? fd1 : sh1;  // the filter's own input history (it pauses while synced)
+				// the filter's input history and state at the step's first sample (a lock inside the step reads them again)
+				const int fd1_in = fd1, fd2_in = fd2;
+				const double y2_in = y2;
+				// (2) + (3'): the lane-parallel evaluation of the average over the step's 64 samples from that state -- the
+				// feed-forward half of iir2::step for the lane's sample (see iir_step_t: x = b0 d(k) + b1 d(k-1) + b2 d(k-2) with
+				// b1 = 2 b0, b2 = b0), then whb_scan_step
+				auto scan_step = [&]() -> double {
+					const int devm1f = ln == 0 ? fd1_in : sh1;  // the filter's own input history (it pauses while synced)
 					const int sh2 = wave_shr1(devm1f);
-					const int devm2f = ln == 0 ? fd2 : sh2;
+					const int devm2f = ln == 0 ? fd2_in : sh2;
 					const double t0 = bh * (double)dev, t1 = bh * (double)devm1f, t2 = bh * (double)devm2f;
-					const double ffp = __builtin_fma(2.0, t1, t0);  // P; B2 = t2
+					return whb_scan_step(scan, __builtin_fma(2.0, t1, t0) + t2, y1_in, y2_in);
+				};
+				if (!was_synced) {
 #ifdef TFREC_AMD_PROFILE_WHB
 					const long long pf_a = __builtin_readcyclecounter();
 					pf_usteps++;
 					pf_top += pf_a - pf_mark;
 #endif
 					if (EXACT) {
+						// ---- (2) feed-forward half of iir2::step for the lane's sample (see iir_step_t)
+						const int devm1f = ln == 0 ? fd1 : sh1;  // the filter's own input history (it pauses while synced)
+						const int sh2 = wave_shr1(devm1f);
+						const int devm2f = ln == 0 ? fd2 : sh2;
+						const double t0 = bh * (double)dev, t1 = bh * (double)devm1f, t2 = bh * (double)devm2f;
+						const double ffp = __builtin_fma(2.0, t1, t0);  // P; B2 = t2
 						// ---- (3) the serial feedback recurrence, 64 samples (a window's last, partial step runs it over whatever
 						// follows the window: finite numbers, never looked at): whb_chain_asm.h.  The feed-forward pairs as four
 						// row-replicated sets: lane 16r + i holds sample 16j + i of set j.
@@ -3073,9 +3092,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 							pf_rec += pf_mark - pf_a;
 #endif
 					} else {
-						// ---- (3') all 64 samples at once (whb_scan_step): x = b0 d(k) + b1 d(k-1) + b2 d(k-2) with b1 = 2 b0, b2 = b0
-						const double x = ffp + t2;
-						ym = whb_scan_step(scan, x, y1, y2);
+						// ---- (3') all 64 samples at once
+						ym = scan_step();
 						y1 = readlane_f64(ym, nv - 1);
 						y2 = nv > 1 ? readlane_f64(ym, nv > 1 ? nv - 2 : 0) : y1_in;
 #ifdef TFREC_AMD_PROFILE_WHB
@@ -3195,6 +3213,12 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 #endif
 				// ---- (5) the step's state
 				const int dl1 = __builtin_amdgcn_readlane(dev, nv - 1);
+				if (!EXACT && !was_synced) {  // the samples of this step the average ran on: up to the lock, or all of them
+					const int nvf = locked_at >= 0 ? locked_at + 1 : nv;
+					if (ln < nvf)
+						dense[dcount + ln] = dev;
+					dcount += nvf;
+				}
 				if (!was_synced && locked_at < 0) {  // the whole step went through the average
 					fd2 = nv > 1 ? __builtin_amdgcn_readlane(dev, nv > 1 ? nv - 2 : 0) : fd1;
 					fd1 = dl1;
@@ -3299,6 +3323,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			r.meta = kWhbRecEnd;
 			r.avgf = 0;
 			recrow[vstep] = r;
+			T.whbdense_n[s] = dcount;
 		}
 		if (ln == 0) {
 			const uint32_t lw = drow[M - 1];
@@ -3322,6 +3347,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			r.meta = kWhbRecEnd;
 			r.avgf = 0;
 			T.whbrec[(size_t)s * T.whbrec_stride] = r;
+			T.whbdense_n[s] = 0;
 		}
 		ChainState &st = L.states[a][s];
 		const uint32_t lw = dec[(size_t)s * dec_stride + M - 1];
@@ -3633,6 +3659,8 @@ __global__ __launch_bounds__(256) TFREC_LAT_VGPR_ATTR void whb_verify_kernel(con
 		T.whbfail[s] = bad ? 1 : 0;
 	}
 }
+
+#include "whb_check.h"
 
 // ------------------------------------------------------------------------------------------------ K5
 // decoder::store_bit / flush for TFA_1 and the TFA_2 family, in two stages:
@@ -4100,9 +4128,22 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 			TRY(hipStreamWaitEvent(P.vx, P.ev_aux, 0));
 		}
 		mark(26, P.vx);
-		if (!(skip & 16))
-		hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 15) / 16), dim3(256), 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
-				   T, P.whb_carry);
+		// The check: the exact chain a stream per LANE over the filter's input sequence, then the records against it (whb_check.h);
+		// TFREC_AMD_WHB_CHECK_ROWS=1: rounds 3-5's kernel, a stream per row of 16 lanes
+		static const int check_rows = TFREC_KNOB_INT("WHB_CHECK_ROWS", 0, 0, 1);
+		if (check_rows) {
+			if (!(skip & 16))
+			hipLaunchKernelGGL(whb_verify_kernel, dim3((n_streams + 15) / 16), dim3(256), 0, P.vx, dev32, n_streams, n_blocks, L, whb_verify,
+					   T, P.whb_carry);
+		} else {
+			static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&whb_chain_kernel),
+									     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChkLdsBytes);
+			if (lds_ok != hipSuccess)
+				return lds_ok;
+			hipLaunchKernelGGL(whb_chain_kernel, dim3((n_streams + kChkStreams - 1) / kChkStreams), dim3(64 * (1 + kChkProducers)), kChkLdsBytes,
+					   P.vx, n_streams, L, whb_verify, T);
+			hipLaunchKernelGGL(whb_check_kernel, dim3(n_streams), block, 0, P.vx, n_streams, L, whb_verify, T, P.whb_carry);
+		}
 		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly -- on the private
 		// state array: the speculative kernels of the submits behind this one work in place on the live one meanwhile
 		ChainLaunch Lr = L;
@@ -4189,15 +4230,27 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 					 n_blocks, P.fmdev_wmax, P.fm_flag_eps));
 			mark(25, P.k2);
 		}
-		mark(1, P.k2);
+		// The speculative pass needs the discriminator pass and the window scan of ITS submit only (every segment starts from
+		// zero): on a stream of its own (ks) it runs beside the repair passes and the chain walk of the submit before, which
+		// stay on k2 -- k2 carried 5.3 ms of kernels per 5.5 ms period (spec 2.4, repairs 1.3-1.9 + 0.9, walk 0.1-0.6).
+		hipStream_t sp = (P.ks && P.fq && P.fmdev_wmax > 0 && !fm_on_kw) ? P.ks : P.k2;
+		if (sp != P.k2) {
+			TRY(hipStreamWaitEvent(sp, P.ev_win, 0));
+			TRY(hipStreamWaitEvent(sp, P.ev_fm, 0));
+		}
+		mark(1, sp);
 		if (!(skip & 128))
-		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize + lds_pad_spec, P.k2, dec, dec_stride, fmdev, fmdev_stride,
+		hipLaunchKernelGGL((spec_biquad_kernel<false, 0>), dim3(spec_blocks), block, K3Tile<false>::kSize + lds_pad_spec, sp, dec, dec_stride, fmdev, fmdev_stride,
 				   n_streams, n_blocks, L, T, ld16, dev32, lanes_win);
-		mark(2, P.k2);
+		mark(2, sp);
+		if (sp != P.k2) {
+			TRY(hipEventRecord(P.ev_spec, sp));
+			TRY(hipStreamWaitEvent(P.k2, P.ev_spec, 0));
+		}
 		if (has_tfa1 && !TFREC_KNOB_INT("T1_EARLY", 0, 0, 1 << 30)) {
 			// TFA_1 needs no biquad stage and has slack: its chain starts once the speculative biquad pass (on the
 			// critical path of the other chains) has had the chip to itself
-			TRY(hipEventRecord(P.ev_fork, P.k2));
+			TRY(hipEventRecord(P.ev_fork, sp));
 			TRY(hipStreamWaitEvent(P.t1, P.ev_fork, 0));
 			t1_waits = true;
 		}

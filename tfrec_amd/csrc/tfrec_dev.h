@@ -274,6 +274,16 @@ struct WinTables {
 	uint32_t *whbseen;           // [n_streams] whbgen[s] as whb_demod_kernel<false> saw it before it read the state
 	uint32_t *whbgen;            // [n_streams] redone submits of the stream so far (ONE array per context)
 	ChainState *whbX;            // [n_streams] the chain state after the stream's last redone submit (ONE array per context)
+	// ... round 6 (whb_check.h): the check as an exact chain PER LANE.  whb_demod_kernel<false> also writes the filter's INPUT SEQUENCE
+	// of the stream -- the stage-1 output of every sample the decision-level average ran on, in order, whatever window and step
+	// it came from (the filter does not know about either: it pauses while the decoder is locked and goes on where it stopped) --
+	// and whb_chain_kernel walks it 64 inputs a round, a stream per lane:
+	int32_t *whbdense;             // [n_streams * whbdense_stride] the sequence
+	int32_t whbdense_stride;       // M + 64
+	int32_t *whbdense_n;           // [n_streams] its length in this submit
+	unsigned long long *whbxbits;  // [n_streams * whbx_stride] round r: bit k = the exact "dev < (int)avg" (whb.cpp:654, 662) of input 64 r + k
+	double2 *whbxsnap;             // [n_streams * whbx_stride] round r: (y, y one input earlier) after input 64 r + 63
+	int32_t whbx_stride;           // rounds a stream can have in one submit + 2
 	int32_t whb_force_fail;      // tests (TFREC_AMD_WHB_FORCE_FAIL=N): declare every N-th (stream + submit) failed
 	int32_t whb_submit_seq;
 	// The redo works on a PRIVATE copy of the stream's chain state (whbscr, ONE array per context: redos run one after the
@@ -311,6 +321,8 @@ struct PipeCtl {
 	// run on cz beside the short windows' slicers on cs (nullptr: one after the other on cs)
 	hipStream_t cz;
 	hipStream_t fq;            // the discriminator pass's own stream (TFREC_AMD_FMDEV_OWN), or nullptr: at the head of k2
+	hipStream_t ks;            // the speculative pass of the TFA_2 family's biquads (TFREC_AMD_SPEC_OWN), or nullptr: at the head of k2
+	hipEvent_t ev_spec;        // ... done (ks): the repair passes on k2 start
 	hipEvent_t ev_heads, ev_coop;
 	hipEvent_t done[3];        // end of the submit on cs / aux / t1
 	hipEvent_t *tev;           // optional timing marks (kTimingMarks)
