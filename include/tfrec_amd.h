@@ -217,13 +217,15 @@ typedef struct {
 	uint64_t tfa2_resliced;      /* tfa2 windows sliced again because the last_bit_idx assumption did not hold */
 	uint64_t tfa1_recomputed;    /* 64-sample steps of long TFA_1 windows whose pre-computed peak detector piece did not
 				        start from the true value and were recomputed */
-	uint64_t biquad_repair_slots; /* 32-sample slots the first repair pass ran (a segment has up to 116) */
+	uint64_t biquad_repair_slots; /* 32-sample slots the first repair pass ran (a segment has up to 256: csrc/tfrec_dev.h kSegSlots) */
 	uint64_t whb_respeculated;   /* (stream, submit) pairs whose lane-parallel WHB decision levels did not reproduce the exact
 				        recurrence's decisions and were demodulated again by the exact kernel */
-	uint64_t tfa1_scalar_groups; /* groups of 64 steps (4096 samples) of long windows that the lane-per-step cooperative slicers
-				        left to their scalar walks -- low 32 bits: TFA_1 (entered without a last_bit_idx and a candidate
-				        at a block's second sample, a stale peak-detector piece, > 64 bits in a lane); high 32 bits:
-				        TFA_2 family (more than 16 rounds of re-walking, entered with a block-relative 0) */
+	uint64_t tfa1_scalar_groups; /* groups of 64 steps (4096 samples) of long TFA_1 windows that the lane-per-step cooperative slicer
+				        left to its scalar walk (entered without a last_bit_idx and a candidate at a block's second
+				        sample, a stale peak-detector piece, > 64 bits in a lane) */
+	uint64_t tfa2_scalar_groups; /* ... of the TFA_2 family (more than 16 rounds of re-walking, entered with a block-relative 0) */
+	uint64_t tfa1_vector_groups; /* groups the lane-per-step form did: TFA_1, */
+	uint64_t tfa2_vector_groups; /* TFA_2 family */
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);
 /* Layout of the context's pipeline, named by its number of CHAIN streams: 6 = deep (default: the filter stage of submit

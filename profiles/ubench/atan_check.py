@@ -1,4 +1,4 @@
-"""CPU check of the atan2 approximation in tfrec_amd/csrc/dsp_dev.h (atan2_int): same operation sequence in float64
+"""CPU check of the atan2 approximation in tfrec_amd/csrc/dsp_dev.h (atan2_reduce + atan2_reduced; until round 4: atan2_int): same operation sequence in float64
 (fused multiply-adds emulated in 80-bit), against libm atan2 and an 80-bit reference.  python atan_check.py"""
 import numpy as np
 ld = np.longdouble

@@ -297,6 +297,31 @@ def test_config5_10x_front_end():
         assert total >= 10
 
 
+def test_config5_full_length_batch_of_64_streams():
+    """BASELINE config 5 at the benchmark's submit length (48 blocks, 31.5 M input samples per stream) on a batch of 64 streams --
+    16 distinct ones, each four times: the 10:1 stage against its C restatement on every distinct stream, the events of all 64
+    against the oracle's int16 entry on the 10:1 stage's output, and replicas identical wherever they sit in the batch."""
+    n_unique, copies, n_blocks = 16, 4, 48
+    base = np.stack([synth.gen_stream(53, s, n_blocks, 0x1F, 256, rate_mult=10) for s in range(n_unique)])
+    iq = np.concatenate([base] * copies)
+    n_streams = iq.shape[0]
+    with api.Receiver(n_streams, 0x2F, 500, 0, max_blocks=n_blocks, all_flushes=True, input_10x=True, max_events=n_streams * 400) as r:
+        r.submit(iq)
+        ev = r.drain()
+        assert r.fm_stats()["host_mismatch"] == 0
+        stage0 = [r.stage0(s, n_blocks * 32768) for s in range(n_unique)]
+    ev = ev[np.lexsort((ev["seq"], ev["slot"], ev["stream"]))]
+    total = 0
+    for s in range(n_unique):
+        want = O.decim10(base[s])
+        assert np.array_equal(stage0[s], want), "10:1 stage, stream %d" % s
+        o = O.Oracle(0x2F, 500, 0)
+        o.process_s16(want)
+        for k in range(copies):
+            total += check_stream(ev, s + k * n_unique, o)
+    assert total >= 40 * copies
+
+
 def test_full_size_pipeline_equals_serial_chains_and_replicas():
     """BASELINE-size streams (48 blocks): the window-parallel pipeline and the independent one-lane-per-chain GPU
     implementation must agree on every flush event, and identical input streams must give identical events
@@ -489,7 +514,16 @@ def test_cooperative_slicers_step_per_lane_and_scalar_walk_emit_the_same_bits(ve
         ev = np.concatenate(evs)
         st = r.stats()
     if vec == "0":
-        assert st["tfa1_scalar_groups"] == 0 and st["tfa2_scalar_groups"] == 0  # (groups the lane-per-step form gave up)
+        # (the counters describe the lane-per-step form: nothing to count when it is switched off)
+        assert st["tfa1_scalar_groups"] == 0 and st["tfa2_scalar_groups"] == 0
+        assert st["tfa1_vector_groups"] == 0 and st["tfa2_vector_groups"] == 0
+    else:
+        # the lane-per-step form RAN (a regression that silently routes everything to the scalar walks would pass the bit
+        # comparison below), did most groups, and its fallback was exercised too (the noisy stream: every sample a rejected
+        # candidate, more than 16 rounds of re-walking)
+        assert st["tfa1_vector_groups"] > 0 and st["tfa2_vector_groups"] > 0, st
+        assert st["tfa1_vector_groups"] > st["tfa1_scalar_groups"] and st["tfa2_vector_groups"] > st["tfa2_scalar_groups"], st
+        assert st["tfa1_scalar_groups"] + st["tfa2_scalar_groups"] > 0, st
     n_bits = 0
     for s in range(n_streams):
         o = O.Oracle(0x2F, 500, 0, log_bits=True)

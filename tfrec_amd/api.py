@@ -59,7 +59,8 @@ class Timings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("biquad_segments", C.c_uint64), ("biquad_unconverged", C.c_uint64), ("biquad_serial", C.c_uint64),
                 ("tfa2_resliced", C.c_uint64), ("tfa1_recomputed", C.c_uint64), ("biquad_repair_slots", C.c_uint64),
-                ("whb_respeculated", C.c_uint64), ("tfa1_scalar_groups", C.c_uint64)]
+                ("whb_respeculated", C.c_uint64), ("tfa1_scalar_groups", C.c_uint64), ("tfa2_scalar_groups", C.c_uint64),
+                ("tfa1_vector_groups", C.c_uint64), ("tfa2_vector_groups", C.c_uint64)]
 
 
 class FmStats(C.Structure):
@@ -286,11 +287,7 @@ class Receiver:
         """Counters of the speculative stages (how the work was done; results never depend on them)."""
         st = Stats()
         _check(self.L, self.L.tfrec_amd_get_stats(self.h, C.byref(st)))
-        d = {n: int(getattr(st, n)) for n, _ in Stats._fields_}
-        # (one counter, two halves: groups of 64 steps the lane-per-step cooperative slicers left to their scalar walks)
-        d["tfa2_scalar_groups"] = d["tfa1_scalar_groups"] >> 32
-        d["tfa1_scalar_groups"] &= 0xFFFFFFFF
-        return d
+        return {n: int(getattr(st, n)) for n, _ in Stats._fields_}
 
 
 def fm_dev_nrzs_probe(records: np.ndarray, device: int = 0) -> np.ndarray:

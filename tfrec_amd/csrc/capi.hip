@@ -1455,11 +1455,12 @@ int tfrec_amd_get_stats(tfrec_amd_ctx *c, tfrec_amd_stats *out)
 	int rc = tfrec_amd_sync(c);
 	if (rc)
 		return rc;
-	static_assert(sizeof(tfrec_amd_stats) == 8 * sizeof(uint64_t), "eight counters");
+	constexpr int kCounters = (int)(sizeof(tfrec_amd_stats) / sizeof(uint64_t));
+	static_assert(sizeof(tfrec_amd_stats) == 11 * sizeof(uint64_t) && kCounters <= 16, "the counters are the first slots of WinTables::stats");
 	for (int k = 0; k < kSets; k++) {  // the table sets count separately
 		tfrec_amd_stats part;
 		HIPCHK(hipMemcpy(&part, c->win[k].stats, sizeof(part), hipMemcpyDeviceToHost));
-		for (int i = 0; i < 8; i++)
+		for (int i = 0; i < kCounters; i++)
 			reinterpret_cast<uint64_t *>(out)[i] += reinterpret_cast<const uint64_t *>(&part)[i];
 	}
 	return TFREC_AMD_OK;

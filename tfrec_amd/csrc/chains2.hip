@@ -90,6 +90,17 @@ __device__ __forceinline__ void latency_prio()
 		__builtin_amdgcn_s_setprio(TFREC_AMD_LAT_PRIO);
 }
 
+// tfrec_amd_stats counters of the cooperative slicers (slots of WinTables::stats; one lane adds).  The statistics builds
+// (-DTFREC_AMD_COOPSTAT / _VECSTAT / _PROFILE_WHB) use the same slots for their own figures: there the counters are left out.
+constexpr int kStatTfa1Scalar = 7, kStatTfa2Scalar = 8, kStatTfa1Vector = 9, kStatTfa2Vector = 10;
+__device__ __forceinline__ void stat_group(const WinTables &T, int slot)
+{
+#if !defined(TFREC_AMD_COOPSTAT) && !defined(TFREC_AMD_VECSTAT) && !defined(TFREC_AMD_PROFILE_WHB)
+	if ((threadIdx.x & 63) == 0)
+		atomicAdd(&T.stats[slot], 1ull);
+#endif
+}
+
 // demodulator::start (decoder.cpp:118-122) applied once per block boundary between two blocks
 __device__ __forceinline__ int rebase_lbi(int lbi, int from_block, int to_block)
 {
@@ -2019,10 +2030,10 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		for (int pos = g1; pos <= last;) {
 			if (bitcnt >= 10) {
 				if (!group_vec(pos)) {
-#ifndef TFREC_AMD_COOPSTAT
-					atomicAdd(&T.stats[7], lane == 0 ? (1ull << 32) : 0ull);  // (high half: TFA_2-family groups left to the scalar walk)
-#endif
+					stat_group(T, kStatTfa2Scalar);  // a group left to the scalar walk (tfrec_amd_get_stats)
 					old_range(pos, pos + 4096);
+				} else {
+					stat_group(T, kStatTfa2Vector);
 				}
 				pos += 4096;
 			} else {  // the thresholds still adapt (a head that gave up): stretch by stretch
@@ -2283,12 +2294,12 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 				}
 			}
 		}
-		if (done)
+		if (done) {
+			stat_group(T, kStatTfa1Vector);
 			continue;
-#ifndef TFREC_AMD_COOPSTAT
+		}
 		if (use_vec)
-			atomicAdd(&T.stats[7], lane == 0 ? 1ull : 0ull);  // groups left to the scalar walk (tfrec_amd_get_stats)
-#endif
+			stat_group(T, kStatTfa1Scalar);  // a group left to the scalar walk (tfrec_amd_get_stats)
 		bool piece_ok = false;
 		MarkPiece mp = { 0, 0, 0, 0 };
 		for (int step = sb; step < sb + ng; step++) {
@@ -3010,7 +3021,9 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				ent[nent] = (uint16_t)v16;
 				nent++;
 			};
-			// the lane's decimated sample of this step and the next (rssi: only while the decoder is locked)
+			// the lane's decimated sample of this step and the next (rssi: only while the decoder is locked).  (Round 6 tried the sum
+			// at the window's end instead, a loop over its locked samples: its loads' latency, microseconds inside the batch, is
+			// then exposed per iteration -- the kernel 20 % longer, profiles/r06_ab_power_sum.txt)
 			auto iq_load = [&](int i) -> uint32_t {
 				const int g = og + kStep * i + ln;
 				return drow[g < M ? g : M - 1];

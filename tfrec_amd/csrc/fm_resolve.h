@@ -3,8 +3,8 @@
 // against libm); plain IEEE fp64 with explicit fma, no contraction (-ffp-contract=off on both sides).
 //
 // The reference computes  r = (int)( atan2(cj, cr) * K ),  K = 16384 * fl(1/pi),  in double.  For generic directions
-// (cr, cj nonzero integers below 2^32, |cr| != |cj|) the fast path (dsp_dev.h: atan2_int) knows the scaled angle to
-// 4e-12; when that is within 1e-9 of an integer k the truncation is decided HERE, exactly:
+// (cr, cj nonzero integers below 2^32, |cr| != |cj|) the fast path (dsp_dev.h: atan2_reduce + atan2_reduced) knows the scaled angle to
+// 6e-12; when that is within 1e-9 of an integer k the truncation is decided HERE, exactly:
 //
 //   1. a_k := the smallest double a with fl(a * K) >= k (found by stepping from fl(k / K)): the reference returns
 //      +-k iff its atan2 result R satisfies R >= a_k, else +-(k - 1).

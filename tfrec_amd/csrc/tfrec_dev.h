@@ -7,6 +7,18 @@
 
 #include "../../include/tfrec_amd.h"
 
+// The kernels are written for ONE target: wave64 throughout, DPP row operations, v_pk_fma_f32 under a
+// wave-wide rounding mode, v_dot2_i32_i16, v_permlane16/32_swap, hand-written GCN assembly.  Any other --offload-arch
+// would fail in the assembler or, worse, compile to something else under wave32.
+#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__)
+#error "tfrec_amd: the device code targets gfx950 (MI355X) only"
+#endif
+#if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "tfrec_amd: the device code assumes 64-lane wavefronts"
+#endif
+#endif
+
 namespace tfrec {
 
 constexpr int kBlockDec = TFREC_AMD_BLOCK_DEC;  // 8192 decimated pairs per reference block

@@ -65,6 +65,9 @@ __global__ __launch_bounds__(64 * (1 + kChkProducers)) void whb_chain_kernel(int
 #ifdef TFREC_AMD_CHK_CLAIM  // the whole register file of its SIMD: no other wave beside the chain (experiment)
 		asm volatile("" ::: "v255", "a255");
 #endif
+#ifdef TFREC_AMD_CHK_PRIO  // (experiment)
+		__builtin_amdgcn_s_setprio(TFREC_AMD_CHK_PRIO);
+#endif
 		double y1 = 0.0, y2 = 0.0;
 		if (my_on) {
 			const WhbExact st = T.whbx[my_s];
@@ -138,10 +141,16 @@ __global__ __launch_bounds__(64 * (1 + kChkProducers)) void whb_chain_kernel(int
 			h2[q] = __builtin_amdgcn_readfirstlane(st.fd2);
 		}
 		int cur[kChkPerProducer], nxt[kChkPerProducer];  // the lane's input of the round being laid out / of the one after it
+#ifdef TFREC_AMD_CHK_PF3  // (experiment: loads three rounds ahead)
+		int nx2[kChkPerProducer];
+#endif
 #pragma unroll
 		for (int q = 0; q < kChkPerProducer; q++) {
 			cur[q] = rounds[q] > 0 ? row[q][ln] : 0;
 			nxt[q] = rounds[q] > 1 ? row[q][64 + ln] : 0;
+#ifdef TFREC_AMD_CHK_PF3
+			nx2[q] = rounds[q] > 2 ? row[q][128 + ln] : 0;
+#endif
 		}
 		auto lay_out = [&](ChkBuf &b, int r) {  // round r from cur[] (h1, h2: the inputs 64 r - 1, 64 r - 2)
 #pragma unroll
@@ -166,17 +175,31 @@ __global__ __launch_bounds__(64 * (1 + kChkProducers)) void whb_chain_kernel(int
 		for (int r = 0; r < rmax; r++) {
 			// round r + 1 is in nxt[]; the loads of round r + 2 go out before it is laid out
 			int far[kChkPerProducer];
+#ifdef TFREC_AMD_CHK_PF3
+#pragma unroll
+			for (int q = 0; q < kChkPerProducer; q++)
+				far[q] = r + 3 < rounds[q] ? row[q][64 * (r + 3) + ln] : 0;
+#else
 #pragma unroll
 			for (int q = 0; q < kChkPerProducer; q++)
 				far[q] = r + 2 < rounds[q] ? row[q][64 * (r + 2) + ln] : 0;
+#endif
 #pragma unroll
 			for (int q = 0; q < kChkPerProducer; q++)
 				cur[q] = nxt[q];
 			if (r + 1 < rmax)
 				lay_out(buf[(r + 1) & 1], r + 1);
+#ifdef TFREC_AMD_CHK_PF3
+#pragma unroll
+			for (int q = 0; q < kChkPerProducer; q++) {
+				nxt[q] = nx2[q];
+				nx2[q] = far[q];
+			}
+#else
 #pragma unroll
 			for (int q = 0; q < kChkPerProducer; q++)
 				nxt[q] = far[q];
+#endif
 			__syncthreads();
 		}
 	}
