@@ -90,14 +90,23 @@ __device__ __forceinline__ void latency_prio()
 		__builtin_amdgcn_s_setprio(TFREC_AMD_LAT_PRIO);
 }
 
-// tfrec_amd_stats counters of the cooperative slicers (slots of WinTables::stats; one lane adds).  The statistics builds
-// (-DTFREC_AMD_COOPSTAT / _VECSTAT / _PROFILE_WHB) use the same slots for their own figures: there the counters are left out.
+// tfrec_amd_stats counters of the cooperative slicers: counted per wave in registers and added to WinTables::stats ONCE, when the
+// wave ends (an atomic per group -- 180 k per batch on two addresses -- queued up in the L2 and every wave's next wait on
+// memory sat behind it: the batch 25 % longer, profiles/r06_ab_power_sum.txt).  The statistics builds (-DTFREC_AMD_COOPSTAT /
+// _VECSTAT / _PROFILE_WHB) use the same slots for their own figures: there the counters are left out.
 constexpr int kStatTfa1Scalar = 7, kStatTfa2Scalar = 8, kStatTfa1Vector = 9, kStatTfa2Vector = 10;
-__device__ __forceinline__ void stat_group(const WinTables &T, int slot)
+struct GroupStats {
+	int scalar, vector;  // groups of 64 steps left to the scalar walk / done a step per lane (wave-uniform)
+};
+__device__ __forceinline__ void stat_flush(const WinTables &T, const GroupStats &g, int slot_scalar, int slot_vector)
 {
 #if !defined(TFREC_AMD_COOPSTAT) && !defined(TFREC_AMD_VECSTAT) && !defined(TFREC_AMD_PROFILE_WHB)
-	if ((threadIdx.x & 63) == 0)
-		atomicAdd(&T.stats[slot], 1ull);
+	if ((threadIdx.x & 63) == 0) {
+		if (g.scalar)
+			atomicAdd(&T.stats[slot_scalar], (unsigned long long)g.scalar);
+		if (g.vector)
+			atomicAdd(&T.stats[slot_vector], (unsigned long long)g.vector);
+	}
 #endif
 }
 
@@ -1562,7 +1571,7 @@ __device__ __forceinline__ void coop_join_bits(CoopBits &bw, uint32_t *__restric
 
 __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					  size_t dec_stride, const int16_t *__restrict__ ld16, const ChainLaunch &L,
-					  const WinTables &T, uint32_t *__restrict__ stage, bool fresh = false, int fresh_lbi = 0)
+					  const WinTables &T, uint32_t *__restrict__ stage, GroupStats &gs, bool fresh = false, int fresh_lbi = 0)
 {
 	const int lane = threadIdx.x;
 	const int a = c / n_streams, s = c - a * n_streams;
@@ -2030,10 +2039,10 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 		for (int pos = g1; pos <= last;) {
 			if (bitcnt >= 10) {
 				if (!group_vec(pos)) {
-					stat_group(T, kStatTfa2Scalar);  // a group left to the scalar walk (tfrec_amd_get_stats)
+					gs.scalar++;  // a group left to the scalar walk (tfrec_amd_get_stats)
 					old_range(pos, pos + 4096);
 				} else {
-					stat_group(T, kStatTfa2Vector);
+					gs.vector++;
 				}
 				pos += 4096;
 			} else {  // the thresholds still adapt (a head that gave up): stretch by stretch
@@ -2103,7 +2112,7 @@ __device__ __forceinline__ void coop_tfa2(int c, int j, int n_streams, int M, co
 // instead of ~7000.  mark_kernel's pieces (16 steps each) are checked for the whole group first.
 __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, const uint32_t *__restrict__ dec,
 					  size_t dec_stride, const ChainLaunch &L, const WinTables &T, int *__restrict__ lds_m,
-					  uint32_t *__restrict__ stage)
+					  uint32_t *__restrict__ stage, GroupStats &gs)
 {
 	const int lane = threadIdx.x;
 	const int a = c / n_streams, s = c - a * n_streams;
@@ -2295,11 +2304,11 @@ __device__ __forceinline__ void coop_tfa1(int c, int j, int n_streams, int M, co
 			}
 		}
 		if (done) {
-			stat_group(T, kStatTfa1Vector);
+			gs.vector++;
 			continue;
 		}
 		if (use_vec)
-			stat_group(T, kStatTfa1Scalar);  // a group left to the scalar walk (tfrec_amd_get_stats)
+			gs.scalar++;  // a group left to the scalar walk (tfrec_amd_get_stats)
 		bool piece_ok = false;
 		MarkPiece mp = { 0, 0, 0, 0 };
 		for (int step = sb; step < sb + ng; step++) {
@@ -2427,14 +2436,16 @@ __global__ __launch_bounds__(64) void coop_slicer_kernel(const uint32_t *__restr
 	const size_t total = (size_t)L.n_active * n_streams * T.cap;
 	const int q = 2 * kind;  // the long windows of this kind
 	const uint32_t count = T.queue[q].count;
+	GroupStats gs = { 0, 0 };
 	for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {  // wave-uniform
 		const uint2 it = T.items[(size_t)q * total + idx];
 		const int c = __builtin_amdgcn_readfirstlane((int)it.x), j = __builtin_amdgcn_readfirstlane((int)it.y);
 		if (kind == 0)
-			coop_tfa1(c, j, n_streams, M, dec, dec_stride, L, T, lds_m, t1_stage);
+			coop_tfa1(c, j, n_streams, M, dec, dec_stride, L, T, lds_m, t1_stage, gs);
 		else
-			coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, t1_stage);
+			coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, t1_stage, gs);
 	}
+	stat_flush(T, gs, kind == 0 ? kStatTfa1Scalar : kStatTfa2Scalar, kind == 0 ? kStatTfa1Vector : kStatTfa2Vector);
 }
 
 constexpr int kWhbRunEsc = 0xffff;            // run-length escape: the next two uint16 hold a 32-bit length
@@ -2927,9 +2938,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 		// the low 32 bits of the difference, and so does this (unsigned: the additions may wrap)
 		uint32_t since = (uint32_t)sgpr((int)(uint32_t)(st.step - st.last_peak));
 		// whb.cpp:678 sums I*I+Q*Q of the synced samples in a double.  The sums are integers far below 2^53, so the
-		// additions are exact in any order: every lane adds its samples' power, the wave sums once per window.
+		// additions are exact in any order: the wave sums a window's samples once, at its end (power_sum).
 		double rssi_d = st.rssi_d;    // rssi collected in earlier submits of a still-open window
-		unsigned long long racc = 0;  // ... and in this submit (per lane)
 		int synced = sgpr(st.synced);
 		// the decoder registers the sync search depends on (store_bit always leaves last_psk == psk, so nrzs toggles
 		// exactly when the bit differs from the previous one: nrzs(t) = bit(t) ^ K with K fixed for the stream)
@@ -2994,7 +3004,6 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			wq += kStep * (kWhbAhead + 1);  // the step the loop loads next
 			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
-				racc = 0;
 				step0 = 0;
 				since = 0;
 			}
@@ -3021,18 +3030,23 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				ent[nent] = (uint16_t)v16;
 				nent++;
 			};
-			// the lane's decimated sample of this step and the next (rssi: only while the decoder is locked).  (Round 6 tried the sum
-			// at the window's end instead, a loop over its locked samples: its loads' latency, microseconds inside the batch, is
-			// then exposed per iteration -- the kernel 20 % longer, profiles/r06_ab_power_sum.txt)
-			auto iq_load = [&](int i) -> uint32_t {
-				const int g = og + kStep * i + ln;
-				return drow[g < M ? g : M - 1];
+			// whb.cpp:677-678: the power of the samples from the one the decoder locked on (or the window's first here, if it began
+			// locked) to the window's last, summed at the window's end (round 6: per step it was two more loads in flight beside
+			// the stage-1 outputs' and their rotation; -1 % of the batch, profiles/r06_ab_power_sum.txt)
+			int rssi_from = synced ? 0 : -1;
+			auto power_sum = [&](int from) -> unsigned long long {
+				unsigned long long acc = 0ull;
+#pragma unroll 4
+				for (int m = from + ln; m < n; m += kStep) {
+					const uint32_t w = drow[og + m];
+					const int I = (int)(int16_t)(w & 0xffff), Q = (int)w >> 16;
+					acc += (unsigned long long)(uint32_t)(I * I + Q * Q);
+				}
+#pragma unroll
+				for (int o = 32; o >= 1; o >>= 1)
+					acc += __shfl_xor(acc, o, 64);
+				return acc;
 			};
-			uint32_t iq0 = 0, iq1 = 0;
-			if (synced) {
-				iq0 = iq_load(0);
-				iq1 = iq_load(1);
-			}
 			for (int i = 0; i < nch; i++) {
 				// ---- (1) this step's inputs; the next two steps' are in flight
 				const int nv = n - kStep * i < kStep ? n - kStep * i : kStep;
@@ -3239,18 +3253,8 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				}
 				last_dev = dl1;
 				since += (uint32_t)nv;
-				if (synced) {  // whb.cpp:677-678: from the sample at which the decoder locked on
-					uint32_t w = iq0;
-					if (locked_at >= 0) {
-						w = iq_load(i);
-						iq1 = iq_load(i + 1);
-					}
-					const int I = (int)(int16_t)(w & 0xffff), Q = (int)w >> 16;
-					if (ln < nv && ln >= locked_at)
-						racc += (unsigned long long)(uint32_t)(I * I + Q * Q);
-					iq0 = iq1;
-					iq1 = iq_load(i + 2);
-				}
+				if (locked_at >= 0)
+					rssi_from = kStep * i + locked_at;
 				cur = nxt[0];
 #pragma unroll
 				for (int k = 0; k + 1 < kWhbAhead; k++)
@@ -3267,10 +3271,7 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			long long rssi_out = 0;
 			if (closed) {  // timeout_cnt reached 0, whb.cpp:691-702
 				if (synced) {
-					unsigned long long tot = racc;
-#pragma unroll
-					for (int o = 32; o >= 1; o >>= 1)
-						tot += __shfl_xor(tot, o, 64);
+					const unsigned long long tot = power_sum(rssi_from);
 					(void)feed(0u, 16);  // 16 x store_bit(0); the flush then clears sr and synced (whb.cpp:559-563)
 					rssi_out = (long long)(rssi_d + (double)tot);
 					res.closed = 1;
@@ -3280,16 +3281,11 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					bc = 0;
 				}
 				rssi_d = 0;
-				racc = 0;
 				step0 = 0;
 				since = 0;
 			} else {  // the window continues in the next submit
-				unsigned long long tot = racc;
-#pragma unroll
-				for (int o = 32; o >= 1; o >>= 1)
-					tot += __shfl_xor(tot, o, 64);
-				rssi_d += (double)tot;
-				racc = 0;
+				if (synced)
+					rssi_d += (double)power_sum(rssi_from);
 				step0 += n;
 			}
 			res.rssi_i = (int32_t)(uint32_t)((unsigned long long)rssi_out & 0xffffffffull);
@@ -3857,7 +3853,8 @@ __device__ __forceinline__ void commit_body(int a, int s, int n_streams, int n_b
 							      // form never gets here: it deferred the chain above)
 						if (lead)
 							atomicAdd(&T.stats[3], 1ull);
-						coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, nullptr, true,
+						GroupStats unused = { 0, 0 };
+						coop_tfa2(c, j, n_streams, M, dec, dec_stride, ld16, L, T, nullptr, unused, true,
 							  rebase_lbi(lbi, lbi_block, og >> 13));
 						__threadfence();  // lane 0's stores (bits, result) before every lane reads them
 						__syncthreads();
