@@ -224,7 +224,8 @@ typedef struct {
 				        left to its scalar walk (entered without a last_bit_idx and a candidate at a block's second
 				        sample, a stale peak-detector piece, > 64 bits in a lane) */
 	uint64_t tfa2_scalar_groups; /* ... of the TFA_2 family (more than 16 rounds of re-walking, entered with a block-relative 0) */
-	uint64_t tfa1_vector_groups; /* groups the lane-per-step form did: TFA_1, */
+	uint64_t tfa1_vector_groups; /* groups the lane-per-step form did (counted by the experiments build of the library only, csrc/knobs.h;
+				        0 otherwise: nearly every wave of the slicers would add to them): TFA_1, */
 	uint64_t tfa2_vector_groups; /* TFA_2 family */
 } tfrec_amd_stats;
 int tfrec_amd_get_stats(tfrec_amd_ctx *ctx, tfrec_amd_stats *out);

@@ -104,8 +104,10 @@ __device__ __forceinline__ void stat_flush(const WinTables &T, const GroupStats 
 	if ((threadIdx.x & 63) == 0) {
 		if (g.scalar)
 			atomicAdd(&T.stats[slot_scalar], (unsigned long long)g.scalar);
+#ifdef TFREC_AMD_EXPERIMENTS  // (nearly every wave has some: 29 k more atomics per launch -- counted where a test asks for them)
 		if (g.vector)
 			atomicAdd(&T.stats[slot_vector], (unsigned long long)g.vector);
+#endif
 	}
 #endif
 }
