@@ -695,6 +695,7 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 	uint32_t *head = MODE == 0 ? &T.queue[q].head : (MODE == 1 ? &T.queue[q].head2 : &T.queue[q].head3);
 	const bool worker = (int)threadIdx.x < lanes;  // the other lanes only help to store
 	bool busy = false, dry = !worker;
+	unsigned long long stat_slots = 0ull;  // tfrec_amd_stats::biquad_repair_slots of this lane's segments (added once, at the end)
 	// the lane's segment
 	int c = 0, count = 0, nslots = 0, min_slots = 0, done = 0, nsamples = 0, loaded = 0;
 	size_t sk = 0;
@@ -824,9 +825,7 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 					T.segend1[sk] = end_of(f);
 				} else if (MODE == 1) {
 					T.segfix[sk] = done | (conv ? kSegConverged : 0);
-#ifndef TFREC_AMD_PROFILE_WHB  // (that build counts the WHB demodulator's cycles in this slot)
-					atomicAdd(&T.stats[5], (unsigned long long)done);
-#endif
+					stat_slots += (unsigned long long)done;
 					if (!conv) {
 						T.segend2[sk] = end_of(f);
 						atomicAdd(&T.stats[1], 1ull);
@@ -847,6 +846,15 @@ __global__ __launch_bounds__(64) void spec_biquad_kernel(const uint32_t *__restr
 		if (busy)
 			fetch(B, ckB);
 		k3_store_t<WHB>(k3_tile, dst);
+	}
+	if (MODE == 1) {  // (one atomic per wave: one per segment -- 50 k a launch on one address -- queues up in the L2, see stat_flush)
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1)
+			stat_slots += __shfl_xor(stat_slots, o, 64);
+#ifndef TFREC_AMD_PROFILE_WHB  // (that build counts the WHB demodulator's cycles in this slot)
+		if ((threadIdx.x & 63) == 0 && stat_slots)
+			atomicAdd(&T.stats[5], stat_slots);
+#endif
 	}
 }
 
