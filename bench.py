@@ -602,7 +602,7 @@ def main():
         traffic = traffic_total = prof_ms = traffic_source = None
         valu = None
         same_workload = (n_streams, n_blocks, a.types, rate) == (1024, 48, 0x2F, 1)
-        ptag = next((t for t in ("r05_final", "r05_mid", "r04_final", "r04_mid", "r03_final", "r03_mid")
+        ptag = next((t for t in ("r06_final", "r05_final", "r05_mid", "r04_final", "r04_mid", "r03_final", "r03_mid")
                      if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
         chain_floor = fe_alone = chain_kernel = None
         utilisation = None
@@ -610,8 +610,11 @@ def main():
             try:  # the dominant kernel = the one with the longest duration ALONE on the chip (committed profile), timed live
                 vj0 = json.load(open(os.path.join(ROOT, "profiles", ptag + "_valu.json")))["kernels"]
                 alone = {}
+                # (the timing field `whb_verify_ms` covers the WHB check, since round 6 whb_chain_kernel + whb_check_kernel)
+                alias = {"whb_chain_kernel": "whb_verify_kernel", "whb_check_kernel": "whb_verify_kernel"}
                 for kn, kv in vj0.items():
                     base = kn.split("<")[0]
+                    base = alias.get(base, base)
                     alone[base] = max(alone.get(base, 0.0), kv.get("kernel_ms_alone") or 0.0)  # (template instances: the longest)
                 cand_ = [kn for kn in sorted(alone, key=alone.get, reverse=True) if kn in kms and kms[kn] > 0]
                 if cand_:
@@ -622,7 +625,7 @@ def main():
                 pass
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", ptag + "_traffic.json")))
-                traffic = tj["kernels"].get(dom_name, {}).get("hbm_bytes")
+                traffic = tj["kernels"].get("whb_chain_kernel" if dom_name == "whb_verify_kernel" else dom_name, {}).get("hbm_bytes")
                 traffic_total = tj.get("total_hbm_bytes_per_batch")
                 traffic_source = "profiles/%s_traffic.json (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" % ptag
             except Exception:
@@ -632,7 +635,7 @@ def main():
                 cand = []
                 for ln in open(os.path.join(ROOT, "profiles", ptag + "_kernel_stats.txt")):
                     f = ln.split()
-                    if len(f) >= 5 and ("tfrec::%s_kernel" % short) in ln and f[-4].isdigit():
+                    if len(f) >= 5 and (("tfrec::%s_kernel" % short) in ln or (short == "whb_verify" and "tfrec::whb_chain_kernel" in ln)) and f[-4].isdigit():
                         cand.append((float(f[-3]), float(f[-2])))
                 if cand:  # (several template instances of one kernel: all launches of a batch together)
                     calls = max(1, sum(1 for _ in cand))
@@ -661,14 +664,15 @@ def main():
                         "issue_busy_over_period": round(vj["issue_roof_ms"] / (elapsed / a.steps * 1e3), 4),
                         "note": ("NOT a roofline: the sum over the batch's kernels (each measured alone) of SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs "
                                  "x 2.36 GHz) = wave-quad-cycles with an instruction of any kind in flight = ~1.1 x (VALU + SALU wave instructions).  "
-                                 "For four and a half rounds the batch period equalled this sum within 1-5 percent; the lane-per-step cooperative slicers "
-                                 "of round 5 took 0.48 G quad-cycles (14 percent) out of it and the period followed by 3-5 percent only: the sum is a "
-                                 "description of how full the SIMDs are, not a bound -- the period now sits on the two serial per-stream WHB kernels "
-                                 "(whb_demod_kernel<false> 5.0 ms inside the batch on its stream, 2.8 ms alone; whb_verify_kernel 4.6 / 3.1), which "
-                                 "run one wave per SIMD of dependent instructions and stretch beside the other chains whatever their priority "
-                                 "(DESIGN.md section 3, 'What binds').  No single resource is saturated (memory controllers ~1/3 busy, VALU issue "
-                                 "~55 percent, clock 2.36 GHz; profiles/r05_*.txt).  What bounds the path nominally is in `roofline` "
-                                 "(hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms); source profile: profiles/" + ptag + "_valu.json"),
+                                 "Rounds 1-4: the batch period equalled this sum within 1-5 percent.  Rounds 5 and 6 took a quarter of the instructions "
+                                 "out (lane-per-step slicers; the WHB check a stream per lane: 312 -> 82 M; the WHB candidate walk) and the period "
+                                 "followed by a third of that: the sum describes how full the SIMDs are, it is not a bound.  The period sits on the "
+                                 "two serial per-stream WHB stages, each busy for the whole period on its stream (whb_demod_kernel<false>: one wave "
+                                 "per stream, 2.4 ms alone, ~5 ms inside the batch; whb_chain_kernel: 3.2 ms alone, ~5 ms inside) and follows what "
+                                 "makes their waves WAIT rather than what they issue (DESIGN.md section 3, 'What binds': 180 k same-address atomics per "
+                                 "batch cost 25 percent, two more loads per step of whb_demod_kernel 20 percent).  No single resource is saturated.  "
+                                 "What bounds the path nominally is in `roofline` (hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms); "
+                                 "source profile: profiles/" + ptag + "_valu.json"),
                         "source": "profiles/%s_valu.json (builder's rocprofv3 --pmc passes; NOT measured in this run)" % ptag,
                     }
                 # the serial floor: the dominant chain kernel ALONE on the chip (serial per stream; consecutive batches'
@@ -730,7 +734,10 @@ def main():
                 "rank_input_crc32": input_crc, "events_all_ranks": events_all,
             },
             "roofline": {
-                "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # (the timing interval `whb_verify` brackets the WHB check: whb_chain_kernel -- all but 0.1-0.3 ms of it -- then
+                # whb_check_kernel and the redo launch, which normally returns at once)
+                "bound": "hbm", "kernel": "whb_chain_kernel" if dom_name == "whb_verify_kernel" else dom_name,
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                 # `kernel` is the kernel with the longest duration ALONE on the chip (a serial per-stream chain that does not
                 # stream the input: its `frac` prices the batch's algorithmic bytes against ITS duration, as the contract asks);
