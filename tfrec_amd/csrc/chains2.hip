@@ -4160,9 +4160,11 @@ hipError_t launch_pipeline(const PipeCtl &P, const uint32_t *dec, size_t dec_str
 									     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChkLdsBytes);
 			if (lds_ok != hipSuccess)
 				return lds_ok;
+			if (!(skip & 16)) {
 			hipLaunchKernelGGL(whb_chain_kernel, dim3((n_streams + kChkStreams - 1) / kChkStreams), dim3(64 * (1 + kChkProducers)), kChkLdsBytes,
 					   P.vx, n_streams, L, whb_verify, T);
 			hipLaunchKernelGGL(whb_check_kernel, dim3(n_streams), block, 0, P.vx, n_streams, L, whb_verify, T, P.whb_carry);
+			}
 		}
 		// ... and the streams it failed (normally none: every workgroup returns at once) again, exactly -- on the private
 		// state array: the speculative kernels of the submits behind this one work in place on the live one meanwhile
