@@ -697,6 +697,19 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 		return prio_env[k] == 'h' ? prio_hi : (prio_env[k] == 'l' ? prio_lo : 0);
 	};
 	auto mkstream = [&](hipStream_t *st, int k, int dflt) { return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_of(k, dflt)); };
+	// (experiment, TFREC_AMD_FS_CUS=n: the front end's stream confined to n of the chip's compute units (a CU mask; such a stream has
+	// normal priority) -- at high priority its 196 k workgroups hold the workgroup dispatcher for their whole duration and nothing else
+	// STARTS meanwhile: profiles/r06_final_steps.txt)
+	auto mk_fs = [&]() -> hipError_t {
+		const int ncu = TFREC_KNOB_INT("FS_CUS", 0, 0, 256);
+		if (ncu <= 0)
+			return mkstream(&c->fs, 0, prio_fs);
+		uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		const int stride = TFREC_KNOB_INT("FS_CU_STRIDE", 1, 1, 8);  // 1: the lowest n bits; k: every k-th bit
+		for (int i = 0, set = 0; i < 256 && set < ncu; i += stride, set++)
+			mask[i >> 5] |= 1u << (i & 31);
+		return hipExtStreamCreateWithCUMask(&c->fs, 8, mask);
+	};
 	if (rc == TFREC_AMD_OK) {
 		// zero FIR history == u8 value 128 (decimate::decimate zeroes hist0, dsp_stuff.cpp:145-152)
 		EventBuf eb;
@@ -709,7 +722,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 				  hipMemset(c->d_tail10[1], 0x80, n * 112) != hipSuccess)) ||
 		    hipMemset(c->d_eb_fresh, 0, kEvFreshBytes) != hipSuccess ||
 		    hipMemcpy(c->d_eb_fresh, &eb, sizeof(eb), hipMemcpyHostToDevice) != hipSuccess ||
-		    mkstream(&c->fs, 0, prio_fs) != hipSuccess ||
+		    mk_fs() != hipSuccess ||
 		    mkstream(&c->cp, 1, 0) != hipSuccess ||
 		    mkstream(&c->cs, 2, prio_hi) != hipSuccess ||
 		    false)

@@ -32,6 +32,7 @@
 
 #include "dsp_dev.h"
 #include "knobs.h"
+#include <algorithm>
 
 namespace tfrec {
 
@@ -45,11 +46,18 @@ typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // 16
 // IN16 = false: raw input is u8 IQ, x = (u8 - 128) << 6 (engine.cpp:77-78).  IN16 = true: the input already is
 // int16 (I,Q) pairs at 1.536 MS/s (what decim10_kernel produces for BASELINE config 5): 4 bytes per complex
 // sample instead of 2, per-tap (x*h)>>16 without the <<6 shortcut.
+// The front end runs as kFrontPersist PERSISTENT workgroups that take the tiles in turn (round 6).  As a workgroup per tile its
+// grid is 196 k workgroups on the context's highest-priority stream: they hold the workgroup dispatcher until the last one is
+// placed, and for those ~2 ms of every period no kernel of another stream STARTS (profiles/r06_final_steps.txt: everything
+// begins in the moment the front end ends).  At lower priority the front end starves instead (rounds 4 and 6).  With a few
+// workgroups per CU placed at once its queue is empty, the others start beside it: -3 % (profiles/r06_ab_front_end_dispatch.txt).
+constexpr int kFrontPersist = 2048;
 template <bool IN16>
 __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	const uint8_t *__restrict__ iq, size_t stride, int m_total, const uint8_t *__restrict__ tail_in,
 	uint8_t *__restrict__ tail_out, uint32_t *__restrict__ dec, size_t dec_stride,
-	unsigned long long *__restrict__ mask, size_t mask_stride, uint32_t *__restrict__ prevdec, int thresh, FrontTaps taps)
+	unsigned long long *__restrict__ mask, size_t mask_stride, uint32_t *__restrict__ prevdec, int thresh, FrontTaps taps,
+	int n_streams, int persist)
 {
 	constexpr int kB = IN16 ? 2 : 1;             // bytes per rail sample
 	constexpr int kTail = kTailBytes * kB;      // history bytes (56 complex samples)
@@ -57,11 +65,6 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 	typedef float f32x4 __attribute__((ext_vector_type(4)));
 	__shared__ __attribute__((aligned(16))) f32x2 y1[kY1Count];  // stage-1 outputs as (I, Q) pairs of floats
 	const float kMagic = 12582912.0f;  // 2^23 + 2^22, see stage 1
-
-	const int s = blockIdx.y;
-	const int tile = blockIdx.x;
-	const int tid = threadIdx.x;
-	const int m0 = tile * kTileDec;
 	const long nbytes = 8L * kB * m_total;
 	// MODE.FP_ROUND (fp32) = 2, round toward -inf: see stage 1.  Every fp32 operation of this kernel is either one of
 	// those FMAs or exact.
@@ -69,13 +72,26 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 #ifdef TFREC_AMD_FE_PRIO
 	__builtin_amdgcn_s_setprio(TFREC_AMD_FE_PRIO);
 #endif
+	// A workgroup per tile (persist = 0: grid = tiles x streams), or -- TFREC_AMD_FE_PERSIST=n -- n workgroups that take the
+	// tiles in turn: the stream's queue is then empty as soon as they are placed, and other streams' kernels can START beside a
+	// running front end (its 196 k workgroups at high priority hold the dispatcher for their whole duration otherwise)
+	const int ntiles = m_total / kTileDec;
+	const int n_work = persist ? ntiles * n_streams : 1;
+	for (int w = persist ? (int)blockIdx.x : 0; w < n_work; w += persist ? (int)gridDim.x : 1) {
+	const int s = persist ? w / ntiles : (int)blockIdx.y;
+	const int tile = persist ? w - s * ntiles : (int)blockIdx.x;
+	// (the lane index laundered per tile: what the tile derives from it is computed again instead of being kept alive across the
+	// whole loop -- with everything hoisted the kernel needed 153 registers instead of 97, three waves per SIMD instead of five)
+	int tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
+	const int m0 = tile * kTileDec;
 	const uint8_t *src = iq + (size_t)s * stride;
 	// The tile reads raw bytes [8*m0 - 112, 8*m0 + 8*T + 16) (x kB) straight from global memory: a lane's 76 bytes per
 	// stage-1 group overlap its neighbours' (64-byte stride), so the last load of a group hits what the first one of
 	// the next lane brought in; the 112 bytes before the submit come from the previous one's tail, what lies behind its
 	// end is silence (only the last tile's last groups look there, and their outputs are never used).
 	const long base = 8L * kB * m0 - kTail;
-	const bool interior = tile > 0 && tile + 1 < (int)gridDim.x;
+	const bool interior = tile > 0 && tile + 1 < ntiles;
 	const uint32_t silence = IN16 ? 0u : 0x80808080u;
 	auto raw_dword = [&](long bo) -> uint32_t {  // bo: byte offset into the stream, 4-byte aligned; edges only
 		if (bo >= 0 && bo + 4 <= nbytes)
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 		return silence;
 	};
 	// history for the next submit: the last 56 raw complex samples of this one
-	if (tile == (int)gridDim.x - 1 && tid < kTail / 16)
+	if (tile == ntiles - 1 && tid < kTail / 16)
 		*reinterpret_cast<uint4 *>(tail_out + (size_t)s * kTail + 16 * tid) =
 			*reinterpret_cast<const uint4 *>(src + nbytes - kTail + 16 * tid);
 
@@ -310,6 +326,9 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 			acc = __builtin_elementwise_fma(y1[y1_phys(2 + n)], f32x2{ taps.f2[n][0], taps.f2[n][1] }, acc);
 		prevdec[s] = (__float_as_uint(acc.x) & 0xffffu) | (__float_as_uint(acc.y) << 16);
 	}
+	if (persist)
+		__syncthreads();  // the next tile's stage 1 writes the LDS image this tile's stage 2 has just read
+	}
 }
 
 // ---- FM discriminator (fm_dev, dsp_stuff.cpp:284-292) of every decimated sample against its predecessor.  The fp64
@@ -318,12 +337,20 @@ __global__ __launch_bounds__(kFrontThreads) void frontend_kernel(
 // 256 samples (one wave) is computed iff a trigger lies in it or within `wmax` samples before it (wmax = the longest
 // window of the registered demodulators; the first wmax samples always, a window may be open from the previous
 // submit) -- about half of the benchmark workload.  Same 256 x 4 lane layout as the front end.
+constexpr int kFmPersist = 4096;
 __global__ __launch_bounds__(kFmThreads) void fmdev_kernel(const uint32_t *__restrict__ dec, size_t dec_stride,
 							      const unsigned long long *__restrict__ mask, size_t mask_stride,
 							      const uint32_t *__restrict__ prevdec, int16_t *__restrict__ fmdev,
-							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax, double flag_eps)
+							      size_t fmdev_stride, EventBuf *__restrict__ eb, int wmax, double flag_eps,
+							      int ntiles, int n_streams, int persist)
 {
-	const int s = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+	// kFmPersist workgroups that take the tiles in turn, like the front end's (393 k workgroups on a low-priority stream were placed
+	// only when every other queue was empty: 3.3 ms inside the batch for 0.8 ms of work; TFREC_AMD_FMDEV_PERSIST=0: a workgroup per tile)
+	const int n_work = persist ? ntiles * n_streams : 1;
+	for (int wi = persist ? (int)blockIdx.x : 0; wi < n_work; wi += persist ? (int)gridDim.x : 1) {
+	const int s = persist ? wi / ntiles : (int)blockIdx.y, tile = persist ? wi - (wi / ntiles) * ntiles : (int)blockIdx.x;
+	int tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
 	const int m0 = tile * kFmTile;
 	const uint32_t *drow = dec + (size_t)s * dec_stride;
 	// Wave priority 1: the pass heads the TFA_2 family's biquad stream, one of the two chains that end at the period.  At
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(kFmThreads) void fmdev_kernel(const uint32_t *__res
 			const int w = w0 + (tid & 63);
 			const bool hit = w <= w1 && mask[(size_t)s * mask_stride + w] != 0ull;
 			if (__ballot(hit) == 0ull)
-				return;
+				continue;
 		}
 	}
 	const uint4 v = *reinterpret_cast<const uint4 *>(drow + m0 + 4 * tid);
@@ -393,6 +420,7 @@ __global__ __launch_bounds__(kFmThreads) void fmdev_kernel(const uint32_t *__res
 	}
 	*reinterpret_cast<uint2 *>(fmdev + (size_t)s * fmdev_stride + m0 + 4 * tid) =
 		make_uint2(((uint32_t)dv[0] & 0xffffu) | ((uint32_t)dv[1] << 16), ((uint32_t)dv[2] & 0xffffu) | ((uint32_t)dv[3] << 16));
+	}
 }
 
 // ---- BASELINE config 5: 15.36 MS/s u8 IQ -> 1.536 MS/s int16 (I,Q).  The reference has no such stage; it is defined
@@ -528,15 +556,16 @@ hipError_t launch_frontend(hipStream_t st, const uint8_t *iq, size_t stride, int
 			   bool in16)
 {
 	const int m_total = n_blocks * kBlockDec;
-	dim3 grid(m_total / kTileDec, n_streams);
-	// experiment knob: extra dynamic LDS per workgroup (caps the front end's workgroups per CU)
+	// experiment knobs: extra dynamic LDS per workgroup (caps the front end's workgroups per CU); a fixed number of workgroups
 	static const int pad = TFREC_KNOB_INT("FE_LDS_PAD", 0, 0, 64 << 10);
+	static const int persist = TFREC_KNOB_INT("FE_PERSIST", kFrontPersist, 0, 1 << 20);
+	const dim3 grid = persist ? dim3((unsigned)std::min<long>(persist, (long)(m_total / kTileDec) * n_streams)) : dim3(m_total / kTileDec, n_streams);
 	if (in16)
 		hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(kFrontThreads), pad, st, iq, stride, m_total, tail_in, tail_out,
-				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
+				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps, n_streams, persist);
 	else
 		hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(kFrontThreads), pad, st, iq, stride, m_total, tail_in, tail_out,
-				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps);
+				   dec, dec_stride, mask, mask_stride, prevdec, thresh, taps, n_streams, persist);
 	return hipGetLastError();
 }
 
@@ -627,9 +656,10 @@ hipError_t launch_fmdev(hipStream_t st, const uint32_t *dec, size_t dec_stride, 
 			int n_streams, int n_blocks, int wmax, double flag_eps)
 {
 	const int m_total = n_blocks * kBlockDec;
-	dim3 grid(m_total / kFmTile, n_streams);
+	static const int fm_persist = TFREC_KNOB_INT("FMDEV_PERSIST", kFmPersist, 0, 1 << 20);
+	const dim3 grid = fm_persist ? dim3((unsigned)std::min<long>(fm_persist, (long)(m_total / kFmTile) * n_streams)) : dim3(m_total / kFmTile, n_streams);
 	hipLaunchKernelGGL(fmdev_kernel, grid, dim3(kFmThreads), 0, st, dec, dec_stride, mask, mask_stride, prevdec, fmdev,
-			   fmdev_stride, eb, wmax, flag_eps);
+			   fmdev_stride, eb, wmax, flag_eps, m_total / kFmTile, n_streams, fm_persist);
 	// one-wave workgroups: the kernel normally has nothing to do, and a 256-thread workgroup waits until a CU has four
 	// wave slots and their registers free at once -- up to a millisecond on the stream that sets the batch period
 	hipLaunchKernelGGL(fm_resolve_kernel, dim3(512), dim3(64), 0, st, dec, dec_stride, prevdec, fmdev, fmdev_stride, eb,
