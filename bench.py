@@ -602,7 +602,7 @@ def main():
         traffic = traffic_total = prof_ms = traffic_source = None
         valu = None
         same_workload = (n_streams, n_blocks, a.types, rate) == (1024, 48, 0x2F, 1)
-        ptag = next((t for t in ("r06_final", "r05_final", "r05_mid", "r04_final", "r04_mid", "r03_final", "r03_mid")
+        ptag = next((t for t in ("r06_final", "r06_mid", "r05_final", "r05_mid", "r04_final", "r04_mid", "r03_final", "r03_mid")
                      if os.path.exists(os.path.join(ROOT, "profiles", t + "_traffic.json"))), None)
         chain_floor = fe_alone = chain_kernel = None
         utilisation = None
