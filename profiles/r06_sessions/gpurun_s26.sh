@@ -13,5 +13,6 @@ B="python bench.py --steps 60 --warmup 8 --cpu-budget 0 --h2d-steps 0 --parity-s
 for t in 20 21 2e 0f 2f; do
 	$B --types $t 2>/dev/null | line T_$t >> $O/types.txt
 done
+python bench.py > $O/default_bench.json 2> $O/default_bench.err
 for seed in 7201 7202 7203 7204 7205 7206; do timeout 900 python tests/stress_gpu.py $seed 60 2>&1 | tail -1 >> $O/campaign.txt; done
 exit 0
