@@ -24,7 +24,8 @@ LIB_EXP_SO = os.path.join(_PKG, "libtfrec_amd_exp.so")
 HOST_SO = os.path.join(_PKG, "libtfrec_host.so")
 
 HIP_SOURCES = ["frontend.hip", "chains.hip", "chains2.hip", "capi.hip"]
-HIP_HEADERS = ["tfrec_dev.h", "dsp_dev.h", "decoder_dev.h", "fm_resolve.h", "fm_resolve_tables.h", "whb_chain_asm.h", "knobs.h"]
+# every header of csrc/ goes into every object's content hash (the stage headers chains2.hip is cut into included)
+HIP_HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 # -ffp-contract=off: the demodulator biquads must round after every multiply and add (bit-exact parity);
 # no fast-math anywhere.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

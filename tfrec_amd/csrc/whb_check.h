@@ -1,5 +1,5 @@
 // tfrec_amd/csrc/whb_check.h -- WHB stage 2, the check of the speculated decisions as an exact chain PER LANE (round 6).
-// Included by chains2.hip (inside namespace tfrec, behind the WHB helpers).
+// Included by chains2.hip (inside namespace tfrec, behind whb_demod.h and whb_verify.h).
 //
 // whb_demod_kernel<false> speculates the decisions "dev < (int)avg_of" (whb.cpp:654, 662) from a lane-parallel evaluation of
 // iir_avg.  The reference's own recurrence -- iir2::step in its normative association, y = ((B2 + a1 y1) + P) + a2 y2 with
