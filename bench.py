@@ -635,7 +635,9 @@ def main():
                 cand = []
                 for ln in open(os.path.join(ROOT, "profiles", ptag + "_kernel_stats.txt")):
                     f = ln.split()
-                    if len(f) >= 5 and (("tfrec::%s_kernel" % short) in ln or (short == "whb_verify" and "tfrec::whb_chain_kernel" in ln)) and f[-4].isdigit():
+                    # (the live interval `whb_verify` brackets whb_chain_kernel, whb_check_kernel and the redo launch: the same three here)
+                    if len(f) >= 5 and (("tfrec::%s_kernel" % short) in ln or (short == "whb_verify" and (
+                            "tfrec::whb_chain_kernel" in ln or "tfrec::whb_check_kernel" in ln or "whb_demod_kernel<true, true>" in ln))) and f[-4].isdigit():
                         cand.append((float(f[-3]), float(f[-2])))
                 if cand:  # (several template instances of one kernel: all launches of a batch together)
                     calls = max(1, sum(1 for _ in cand))
@@ -746,6 +748,8 @@ def main():
                 # the dominant kernel's duration: live HIP events on its stream (includes its wait for the chip beside the
                 # other streams' kernels) | average of the same kernel in the committed kernel trace, per batch
                 "kernel_ms_hip_events": round(dom_ms, 4), "kernel_ms_profiles": prof_ms,
+                "kernel_ms_covers": (["whb_chain_kernel", "whb_check_kernel", "whb_demod_kernel<true, true>"]
+                                     if dom_name == "whb_verify_kernel" else [dom_name]),
                 "profiles": ("profiles/%s_kernel_stats.txt" % ptag) if ptag and same_workload else None,
                 "valu_profiled": valu,
                 # ---- what binds (period / max(floors) = how far from the roof):
