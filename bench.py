@@ -20,6 +20,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
                   never `value`),
   "ms_min/ms_median/ms_max": per-step dispersion (time between consecutive drains inside the timed region);
   "ms_per_step_steady": the same without the steps in which the FIFO fills and drains.
+  "host_ms":      the host's side of the timed region: every submit's duration, the longest gap between two drains, pauses of
+                  Python's garbage collector (a stalled host starves the pipeline without showing in any kernel's interval).
   "roofline" also states what binds: hbm_floor_ms (2 B per input sample at 8 TB/s), algorithmic_valu_floor_ms (the reference's
                   arithmetic 64 lanes wide at one instruction per SIMD and quad-cycle: derivation above ALG_OPS and in
                   DESIGN.md 3), chain_floor_ms (the longest kernel alone on the chip: the serial WHB chains),
@@ -360,17 +362,37 @@ def main():
         n_bg = int(a.bg_traffic_gb * 1e9 / 2)
         bg = (torch.empty(n_bg, dtype=torch.uint8, device=dev), torch.empty(n_bg, dtype=torch.uint8, device=dev), torch.cuda.Stream(device=dev))
 
+    # host side of a step (ms): every submit's duration, the longest time from a drain's return to the next drain's call, and every
+    # pause of Python's garbage collector inside run() -- a stalled host shows up here, not in the kernels' intervals (round 6:
+    # hipMemcpyAsync of the drain's copy blocked submits 6 and 7 after every synchronize, profiles/r06_host_stalls.txt)
+    host_ms = {"submit_max": 0.0, "between_drains_max": 0.0, "gc_pauses": []}
+    gc_t = [0.0]
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            host_ms["gc_pauses"].append([info.get("generation"), round((time.perf_counter() - gc_t[0]) * 1e3, 3)])
+
     def run(n_steps, collect, src=None, stamps=None):
         n_ev = 0
         queued = 0
+        t_ret = None
         for k in range(n_steps):
             while queued < n_steps and queued - k < depth:
+                ts = time.perf_counter()
                 r.submit(next_batch() if src is None else src)
+                if stamps is not None:
+                    host_ms["submit_max"] = max(host_ms["submit_max"], (time.perf_counter() - ts) * 1e3)
+                    host_ms.setdefault("submit_ms", []).append(round((time.perf_counter() - ts) * 1e3, 3))
                 queued += 1
                 if bg is not None:
                     with torch.cuda.stream(bg[2]):
                         bg[1].copy_(bg[0], non_blocking=True)
+            if stamps is not None and t_ret is not None:
+                host_ms["between_drains_max"] = max(host_ms["between_drains_max"], (time.perf_counter() - t_ret) * 1e3)
             n_ev += len(r.drain())
+            t_ret = time.perf_counter()
             if stamps is not None:
                 stamps.append(time.perf_counter())
             if collect is not None:
@@ -379,15 +401,18 @@ def main():
                     collect.setdefault(kk, []).append(v)
         return n_ev
 
+    import gc
     run(a.warmup, None)
     kt = {}
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
+    gc.callbacks.append(gc_cb)
     t0 = time.perf_counter()
     stamps = [t0]
     n_events = run(a.steps, kt, stamps=stamps)
     torch.cuda.synchronize(dev)
+    gc.callbacks.remove(gc_cb)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -704,6 +729,8 @@ def main():
             "ms_per_step_steady": (round(float(step_ms[depth:-depth].mean()), 4) if len(step_ms) > 2 * depth + 2 else None),
             # (every step of a short run: where the FIFO's filling, a late host or a slow tail went)
             "step_ms": ([round(float(x), 3) for x in step_ms] if len(step_ms) <= 64 else None),
+            "host_ms": {"submit_max": round(host_ms["submit_max"], 3), "between_drains_max": round(host_ms["between_drains_max"], 3),
+                        "submit_ms": host_ms.get("submit_ms", [])[:64] if a.steps <= 64 else None, "gc_pauses": host_ms["gc_pauses"][:16], "gc_pause_total": round(sum(p for _, p in host_ms["gc_pauses"]), 3)},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

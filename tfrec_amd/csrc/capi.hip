@@ -128,6 +128,7 @@ struct tfrec_amd_ctx {
 	tfrec_amd_event *d_events[kSets] = {};
 	EventBuf *d_eb[kSets] = {};
 	uint8_t *d_evblock[kSets] = {}, *h_evblock[kSets] = {};  // what d_eb / d_events and h_eb / h_events point into
+	uint8_t *h_evblock_dev[kSets] = {};                      // the page-locked blocks as the device addresses them (drain_copy_kernel)
 	EventBuf *d_eb_fresh = nullptr;       // { 0, max_events, 0 }: copied over a set's EventBuf when a submit starts
 	// Pinned staging for the drain, one per set: the device-to-host copies of a submit's event buffer are queued on cp
 	// when the submit is made (behind its three end-of-chain events), so they are done when the host comes to drain it.
@@ -170,6 +171,16 @@ struct tfrec_amd_ctx {
 };
 
 namespace {
+// The drain's device-to-host copy as a kernel of our own (16 bytes per lane into the page-locked block, which the device addresses
+// directly).  hipMemcpyAsync did the same with the runtime's copy kernel -- but two or three times after every synchronize (the 6th and
+// 7th submit of the driver's 20-step line) the CALL blocked the host for a whole batch period, now and then for two (13 ms: the pipeline
+// ran dry, 6.2 instead of 5.75 ms per step): profiles/r06_host_stalls.txt.
+__global__ __launch_bounds__(256) void drain_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+		dst[i] = src[i];
+}
+
 struct PoisonGuard {
 	tfrec_amd_ctx *c;
 	bool ok = false;
@@ -675,6 +686,7 @@ int tfrec_amd_create(const tfrec_amd_config *cfg, tfrec_amd_ctx **out)
 #undef ALLOC
 	for (int k = 0; k < kSets && rc == TFREC_AMD_OK; k++) {
 		if (hipHostMalloc((void **)&c->h_evblock[k], kEvHeader + (size_t)cfg->max_events * sizeof(tfrec_amd_event), hipHostMallocDefault) != hipSuccess ||
+		    hipHostGetDevicePointer((void **)&c->h_evblock_dev[k], c->h_evblock[k], 0) != hipSuccess ||
 		    hipEventCreateWithFlags(&c->copied[k], hipEventDisableTiming) != hipSuccess) {
 			rc = TFREC_AMD_E_NOMEM;
 			break;
@@ -1028,8 +1040,21 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 	for (auto &e : c->done[set])
 		HIPCHK(hipStreamWaitEvent(cpy, e, 0));
 	c->copied_n[set] = std::min<uint32_t>(c->copy_guess, (uint32_t)c->cfg.max_events);
-	HIPCHK(hipMemcpyAsync(c->h_evblock[set], c->d_evblock[set], kEvHeader + (size_t)c->copied_n[set] * sizeof(tfrec_amd_event),
-			      hipMemcpyDeviceToHost, cpy));  // header, overflow flag and the first copied_n events in one go
+	{  // header, overflow flag and the first copied_n events in one go
+		static_assert(kEvHeader % 16 == 0 && sizeof(tfrec_amd_event) % 16 == 0, "drain_copy_kernel moves 16 bytes per lane");
+		const size_t bytes = kEvHeader + (size_t)c->copied_n[set] * sizeof(tfrec_amd_event);
+		static const int copy_kernel = TFREC_KNOB_INT("COPY_KERNEL", 1, 0, 1);  // (0: hipMemcpyAsync, as until round 6)
+		if (copy_kernel) {
+			const size_t n16 = bytes / 16;
+			static const int copy_blocks = TFREC_KNOB_INT("COPY_BLOCKS", 256, 1, 4096);
+			const unsigned blocks = (unsigned)std::min<size_t>((size_t)copy_blocks, (n16 + 255) / 256);
+			hipLaunchKernelGGL(drain_copy_kernel, dim3(blocks), dim3(256), 0, cpy, (const uint4 *)c->d_evblock[set],
+					   (uint4 *)c->h_evblock_dev[set], n16);
+			HIPCHK(hipGetLastError());
+		} else {
+			HIPCHK(hipMemcpyAsync(c->h_evblock[set], c->d_evblock[set], bytes, hipMemcpyDeviceToHost, cpy));
+		}
+	}
 	HIPCHK(hipEventRecord(c->copied[set], cpy));
 	if (timing)
 		c->timed = true;
