@@ -170,7 +170,7 @@ struct tfrec_amd_ctx {
 	long hp_n = 0, hp_gap_n = 0;
 };
 
-namespace {
+namespace tfrec {
 // The drain's device-to-host copy as a kernel of our own (16 bytes per lane into the page-locked block, which the device addresses
 // directly).  hipMemcpyAsync did the same with the runtime's copy kernel -- but two or three times after every synchronize (the 6th and
 // 7th submit of the driver's 20-step line) the CALL blocked the host for a whole batch period, now and then for two (13 ms: the pipeline
@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void drain_copy_kernel(const uint4 *__restrict
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
 		dst[i] = src[i];
 }
+}  // namespace tfrec
 
+namespace {
 struct PoisonGuard {
 	tfrec_amd_ctx *c;
 	bool ok = false;
@@ -1048,7 +1050,7 @@ static int submit_common(tfrec_amd_ctx *c, const void *d_iq, size_t stride, int 
 			const size_t n16 = bytes / 16;
 			static const int copy_blocks = TFREC_KNOB_INT("COPY_BLOCKS", 256, 1, 4096);
 			const unsigned blocks = (unsigned)std::min<size_t>((size_t)copy_blocks, (n16 + 255) / 256);
-			hipLaunchKernelGGL(drain_copy_kernel, dim3(blocks), dim3(256), 0, cpy, (const uint4 *)c->d_evblock[set],
+			hipLaunchKernelGGL(tfrec::drain_copy_kernel, dim3(blocks), dim3(256), 0, cpy, (const uint4 *)c->d_evblock[set],
 					   (uint4 *)c->h_evblock_dev[set], n16);
 			HIPCHK(hipGetLastError());
 		} else {
