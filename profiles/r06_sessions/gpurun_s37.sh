@@ -1,4 +1,5 @@
 #!/bin/bash
+# (bench.py carried a temporary --gc-off switch for this session only: the collector never ran inside a timed region, the switch was removed again)
 # round 6 session 37: the slow runs of the driver's line are HOST stalls (session 36's trace: the GPU's copy of batch 8 done at 54.6 ms, the host's drain returns at 64.1):
 # the driver's full command with the host's side timed (host_ms: longest submit, longest gap between drains, garbage collector pauses), 9 times as is and 9 times with
 # Python's cyclic collector off inside the warm-up + timed region, alternating
