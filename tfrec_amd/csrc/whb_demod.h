@@ -26,10 +26,6 @@
 // When the decoder locks at sample k of a step, y(0..k) is already in LDS: the filter state is taken at k and the
 // candidates after k are re-tested against the frozen average -- no rewind.
 // The decoder stages (whb_decode_window, whb_commit_stream) run in the tail, by the same wave.
-#ifndef TFREC_AMD_WHB_AHEAD
-#define TFREC_AMD_WHB_AHEAD 1
-#endif
-constexpr int kWhbAhead = TFREC_AMD_WHB_AHEAD;  // whb_demod_kernel: steps whose stage-1 outputs are held ahead of the current one (one more is being loaded)
 constexpr int kWhbSpb = 64, kWhbSpbShift = 6;  // whb_demod's samples per bit (main.cpp:217), see whb_demod_kernel
 constexpr uint32_t kWhbSyncRev = 0xd2b42bd4u;  // bit-reversed 0x2bd42d4b (whb.cpp:582): newest bit at the LSB
 
@@ -325,12 +321,13 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 			// lane as their offset)
 			const int32_t *wq = dvrow + (size_t)slot0 * 32;
 			uint16_t *ent = reinterpret_cast<uint16_t *>(T.bits + (size_t)c * T.bit_words + (og >> 6) + 3 * j);
-			// kWhbAhead steps stay in flight (past the window's end: the row's next slots or the slack behind it, never used)
-			int cur = wq[ln], nxt[kWhbAhead];
-#pragma unroll
-			for (int k = 0; k < kWhbAhead; k++)
-				nxt[k] = wq[kStep * (k + 1) + ln];
-			wq += kStep * (kWhbAhead + 1);  // the step the loop loads next
+			// The steps' stage-1 outputs travel through a RING of four registers with fixed roles (the loop below is unrolled by four):
+			// step i reads ring[i & 3] and first loads step i + 3 into ring[(i + 3) & 3], the register of the step before.  Three
+			// steps stay in flight (past the window's end: the row's next slots or the slack behind it, never used) and nothing is
+			// ever MOVED: rounds 3-6 rotated cur <- nxt <- newest at the end of every step, and a move of a register whose load is
+			// in flight waits for that load -- and, vmcnt counting in order, for every store of the step: a memory latency per step.
+			int ring0 = wq[ln], ring1 = wq[kStep + ln], ring2 = wq[2 * kStep + ln], ring3 = 0;
+			wq += 3 * kStep;  // the step the loop loads next
 			if (!(j == 0 && cont)) {  // window opens: whb_demod::reset, whb.cpp:616-623
 				rssi_d = 0;
 				step0 = 0;
@@ -376,13 +373,12 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 					acc += __shfl_xor(acc, o, 64);
 				return acc;
 			};
-			for (int i = 0; i < nch; i++) {
-				// ---- (1) this step's inputs; the next two steps' are in flight
+			auto step = [&](const int i, const int dev, int &fill) __attribute__((always_inline)) {
+				// ---- (1) this step's inputs; the next three steps' are in flight
 				const int nv = n - kStep * i < kStep ? n - kStep * i : kStep;
 				const unsigned long long valid = nv < kStep ? (1ull << nv) - 1ull : ~0ull;  // the step's samples inside the window
-				const int nxn = wq[ln];
+				fill = wq[ln];
 				wq += kStep;
-				const int dev = cur;
 				const int sh1 = wave_shr1(dev);
 				const int devm1 = ln == 0 ? last_dev : sh1;  // dev > last_dev (whb.cpp:663): the sample before the step
 				const unsigned long long rise_m = __builtin_amdgcn_ballot_w64(dev > devm1) & valid;
@@ -584,14 +580,21 @@ __global__ __launch_bounds__(64) void whb_demod_kernel(const uint32_t *__restric
 				since += (uint32_t)nv;
 				if (locked_at >= 0)
 					rssi_from = kStep * i + locked_at;
-				cur = nxt[0];
-#pragma unroll
-				for (int k = 0; k + 1 < kWhbAhead; k++)
-					nxt[k] = nxt[k + 1];
-				nxt[kWhbAhead - 1] = nxn;
 #ifdef TFREC_AMD_PROFILE_WHB
 				pf_tail += __builtin_readcyclecounter() - pf_mark;
 #endif
+			};
+			for (int i = 0; i < nch; i += 4) {
+				step(i, ring0, ring3);
+				if (i + 1 >= nch)
+					break;
+				step(i + 1, ring1, ring0);
+				if (i + 2 >= nch)
+					break;
+				step(i + 2, ring2, ring1);
+				if (i + 3 >= nch)
+					break;
+				step(i + 3, ring3, ring2);
 			}
 			// ---- the window's last sample in this submit
 			WinResult res;
