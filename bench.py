@@ -695,7 +695,7 @@ def main():
                                  "out (lane-per-step slicers; the WHB check a stream per lane: 312 -> 82 M; the WHB candidate walk) and the period "
                                  "followed by a third of that: the sum describes how full the SIMDs are, it is not a bound.  The period sits on the "
                                  "two serial per-stream WHB stages, each busy for the whole period on its stream (whb_demod_kernel<false>: one wave "
-                                 "per stream, 2.4 ms alone, ~5 ms inside the batch; whb_chain_kernel: 3.2 ms alone, ~5 ms inside) and follows what "
+                                 "per stream, 2.2 ms alone, ~4.3 ms inside the batch; whb_chain_kernel: 3.2 ms alone, ~5 ms inside) and follows what "
                                  "makes their waves WAIT rather than what they issue (DESIGN.md section 3, 'What binds': 180 k same-address atomics per "
                                  "batch cost 25 percent, two more loads per step of whb_demod_kernel 20 percent).  No single resource is saturated.  "
                                  "What bounds the path nominally is in `roofline` (hbm_floor_ms, algorithmic_valu_floor_ms, chain_floor_ms); "
